@@ -1,0 +1,221 @@
+"""Op-level program builder: turns "conv3x3 of this NHWC operand with that weight" into FridoOp
+descriptors, owning the packed-weight cache and the activation pool.  The U-Net / VQGAN plans
+(unet_plan.py, vqgan_plan.py) are written against this API; the kernel unit tests drive it directly.
+"""
+import torch
+
+from . import _lib
+from .engine import (Operand, POperand, F32, Pool, Prog, pack_matrix, pack_conv_weight, rup)
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+
+
+class Builder:
+    def __init__(self, device, nsplit, weights=None):
+        self.device = torch.device(device)
+        self.nsplit = nsplit
+        self.w = weights or {}          # name -> f32 tensor on device (reference state_dict naming)
+        self.pool = Pool(self.device)
+        self.prog = Prog(self.device, nsplit)
+        self._wcache = {}
+        self._persist = []              # tensors that must outlive the builder's programs
+
+    # ---- programs ------------------------------------------------------------------------------
+    def new_prog(self):
+        self.prog = Prog(self.device, self.nsplit)
+        self.prog.keep.append(self)
+        return self.prog
+
+    # ---- allocation -----------------------------------------------------------------------------
+    def f32(self, rows, C):
+        return F32(self.pool, rows, C)
+
+    def op(self, rows, K, batch=1):
+        return POperand(self.pool, rows, K, self.nsplit, batch=batch)
+
+    def persistent_op(self, rows, K, batch=1, zero=True):
+        o = Operand(rows, K, self.nsplit, self.device, zero=zero, batch=batch)
+        self._persist.append(o)
+        return o
+
+    def persistent_f32(self, *shape, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.device)
+        self._persist.append(t)
+        return t
+
+    def dev_f32(self, name):
+        t = self.w[name]
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.float().contiguous()
+            self.w[name] = t
+        return t
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def conv_weight(self, name):
+        key = ("conv", name)
+        if key not in self._wcache:
+            self._wcache[key] = pack_conv_weight(self.w[name], self.nsplit)
+        return self._wcache[key]
+
+    def lin_weight(self, name, rows=None):
+        """Linear / 1x1-conv weight [N][K] (optionally a row slice) as an operand."""
+        key = ("lin", name, rows)
+        if key not in self._wcache:
+            w = self.w[name]
+            w = w.reshape(w.shape[0], -1)
+            if rows is not None:
+                w = w[rows[0]:rows[1]]
+            self._wcache[key] = pack_matrix(w, self.nsplit)
+        return self._wcache[key]
+
+    def cat_lin_weight(self, key, names):
+        if key not in self._wcache:
+            w = torch.cat([self.w[n].reshape(self.w[n].shape[0], -1) for n in names], dim=0)
+            self._wcache[key] = pack_matrix(w, self.nsplit)
+        return self._wcache[key]
+
+    def bias(self, name):
+        return self.dev_f32(name).data_ptr() if name in self.w else None
+
+    # ---- ops -----------------------------------------------------------------------------------
+    def conv(self, a, B, Hs, Ws, wname, *, stride=1, pad=1, up=0, dn=0, Ho=None, Wo=None, bias=True,
+             rowvec=None, act=ACT_NONE, residual=None, out="f32", alpha=1.0):
+        """3x3 / 1x1 convolution of the NHWC operand `a` ([B*Hs*Ws][Cin_pad]).
+        up: nearest x2^up up-sampling folded in (pyunet.py:119); dn: source sampled at stride 2^dn
+        (spade_norm.py:52 nearest down-resize).  Returns F32 or POperand [B*Ho*Wo][Cout]."""
+        wop, cp = self.conv_weight(wname + ".weight")
+        w = self.w[wname + ".weight"]
+        co, _, kh, kw = w.shape
+        assert a.K == cp, (wname, a.K, cp)
+        Hl, Wl = (Hs << up) >> dn, (Ws << up) >> dn
+        if Ho is None:
+            Ho = (Hl + 2 * pad - kh) // stride + 1
+            Wo = (Wl + 2 * pad - kw) // stride + 1
+        M = B * Ho * Wo
+        geom = dict(Hs=Hs, Ws=Ws, Cin=cp, Hl=Hl, Wl=Wl, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pad=pad,
+                    up_shift=up, dn_shift=dn)
+        return self._gemm_out(M, co, kh * kw * cp, a, wop, conv=geom, bias=self.bias(wname + ".bias") if bias else None,
+                              rowvec=rowvec, act=act, residual=residual, out=out, alpha=alpha)
+
+    def linear(self, a, wname, *, M=None, bias=True, act=ACT_NONE, residual=None, out="f32", rowvec=None,
+               wop=None, bias_ptr=None, alpha=1.0, N=None):
+        """y[M][N] = a[M][K] @ W[N][K]^T (+bias).  `a` is an operand with K == W's padded K."""
+        wop = wop or self.lin_weight(wname + ".weight")
+        M = M if M is not None else a.rows * getattr(a, "batch", 1)
+        N = N or wop.rows
+        assert a.K == wop.K, (wname, a.K, wop.K)
+        if bias_ptr is None and bias:
+            bias_ptr = self.bias(wname + ".bias")
+        return self._gemm_out(M, N, wop.K, a, wop, bias=bias_ptr, rowvec=rowvec, act=act, residual=residual, out=out,
+                              alpha=alpha)
+
+    def _gemm_out(self, M, N, K, a, wop, *, conv=None, bias=None, rowvec=None, act=0, residual=None, out="f32",
+                  alpha=1.0):
+        kw = {}
+        res = None
+        if out == "f32":
+            res = self.f32(M, N)
+            kw.update(out_f32=res.ptr, ldo=N)
+        elif out == "op":
+            res = self.op(M, rup(N, 32))
+            assert rup(N, 32) == N, "operand outputs must have N % 32 == 0 (pad columns would be garbage)"
+            kw.update(out_op=res.ptr, ldoo=res.K, oo_lo=res.lo)
+        elif isinstance(out, tuple):        # ("f32"|"op", existing buffer)
+            kind, res = out
+            if kind == "f32":
+                kw.update(out_f32=res.ptr, ldo=res.C)
+            else:
+                kw.update(out_op=res.ptr, ldoo=res.K, oo_lo=res.lo)
+        if residual is not None:
+            kw.update(residual=residual.ptr, ldr=residual.C)
+        if rowvec is not None:
+            kw.update(rowvec=rowvec["ptr"], rows_per_vec=rowvec["rows_per_vec"], ldv=rowvec["ld"],
+                      rowvec_step=rowvec.get("step"))
+        self.prog.gemm(M, N, K, a, wop, bias=bias, act=act, alpha=alpha, conv=conv, **kw)
+        return res
+
+    def gn_stats(self, x1, x2, B, HW):
+        C = x1.C + (x2.C if x2 is not None else 0)
+        S = max(1, min(64, HW // 64, max(1, 1024 // B)))
+        part = self.pool.alloc(B * S * 32 * 2 * 8)
+        self.prog.emit("FRIDO_OP_GN_STATS", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
+                       C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr())
+        return part, S
+
+    def groupnorm(self, x1, x2, B, HW, wname, eps, *, gamma=None, beta=None, act=ACT_NONE, want_raw=False,
+                  out_f32=False):
+        """GroupNorm(32) [+SPADE] [+SiLU] of the (virtually concatenated) NHWC f32 input -> operand."""
+        C = x1.C + (x2.C if x2 is not None else 0)
+        part, S = self.gn_stats(x1, x2, B, HW)
+        a = self.op(B * HW, C)
+        raw = self.op(B * HW, C) if want_raw else None
+        of = self.f32(B * HW, C) if out_f32 else None
+        self.prog.emit("FRIDO_OP_GN_APPLY", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
+                       C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr(),
+                       eps=eps, weight=self.bias(wname + ".weight"), bias=self.bias(wname + ".bias"),
+                       gamma=gamma.ptr if gamma is not None else None, beta=beta.ptr if beta is not None else None,
+                       act=act, nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo,
+                       raw_op=raw.ptr if raw is not None else None, raw_lo=raw.lo if raw is not None else 0,
+                       out_f32=of.ptr if of is not None else None)
+        self.pool.release(part)
+        if out_f32:
+            return a, raw, of
+        return a, raw
+
+    def layernorm(self, x, wname, eps=1e-5):
+        a = self.op(x.rows, x.C)
+        self.prog.emit("FRIDO_OP_LAYERNORM", x=x.ptr, rows=x.rows, C=x.C, eps=eps, weight=self.bias(wname + ".weight"),
+                       bias=self.bias(wname + ".bias"), nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo)
+        return a
+
+    def softmax(self, s, rows, N, ld, Npad):
+        p = self.op(rows, Npad)
+        self.prog.emit("FRIDO_OP_SOFTMAX", x=s.ptr, rows=rows, N=N, ld=ld, Npad=Npad, nsplit=self.nsplit, out_op=p.ptr,
+                       out_lo=p.lo)
+        return p
+
+    def geglu(self, g, H):
+        o = self.op(g.rows, H)
+        self.prog.emit("FRIDO_OP_GEGLU", x=g.ptr, rows=g.rows, H=H, nsplit=self.nsplit, out_op=o.ptr, out_lo=o.lo)
+        return o
+
+    def pack(self, src_ptr, B, HW, Csrc, c0, Cuse, *, nchw=False, scale=1.0, out=None):
+        cp = rup(Cuse, 32)
+        o = out or self.op(B * HW, cp)
+        self.prog.emit("FRIDO_OP_PACK", src=src_ptr, B=B, HW=HW, Csrc=Csrc, c0=c0, Cuse=Cuse, Cpad=cp, nchw=int(nchw),
+                       scale=scale, nsplit=self.nsplit, out_op=o.ptr, out_lo=o.lo)
+        return o
+
+    def to_operand(self, x):
+        """f32 [rows][C] -> operand (C % 32 == 0)."""
+        return self.pack(x.ptr, 1, x.rows, x.C, 0, x.C)
+
+    def relayout(self, src_ptr, dst_ptr, B, HW, Csrc, c0, Cuse, Cdst, d0, to_nchw):
+        self.prog.emit("FRIDO_OP_RELAYOUT", src=src_ptr, dst=dst_ptr, B=B, HW=HW, Csrc=Csrc, c0=c0, Cuse=Cuse, Cdst=Cdst,
+                       d0=d0, to_nchw=int(to_nchw))
+
+    # ---- attention (single head, unfused: QK^T -> softmax -> PV on the MFMA GEMM) -----------------
+    def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0):
+        """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
+        [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158)."""
+        Np = rup(Nk, 32)
+        s = self.f32(B * Nq, Nk)
+        self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
+                       a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)
+        p = self.softmax(s, B * Nq, Nk, Nk, Np)
+        s.free()
+        o = self.op(B * Nq, d)
+        self.prog.gemm(Nq, d, Np, p, vT, batch=B, lda=Np, ldb=Np, a_bs=Nq * Np, b_bs=d * Np, out_op=o.ptr,
+                       oo_bs=Nq * d, ldoo=d, oo_lo=o.lo)
+        p.free()
+        return o
+
+    def v_transposed(self, x, ldx, wop, B, Nk, d, *, bias_ptr=None, out=None, x_off=0):
+        """vT[z][d][Nk_pad] = (W_v @ x[z]^T): the value projection written transposed so that PV is an
+        NT GEMM.  `out` must be a zero-initialised persistent operand (pad columns stay zero)."""
+        Np = rup(Nk, 32)
+        vT = out or self.persistent_op(d, Np, batch=B, zero=True)
+        # bias of a transposed projection is per ROW (per output channel)
+        self.prog.gemm(d, Nk, wop.K, wop, (x.ptr + 2 * x_off, x.lo), batch=B, lda=wop.K, ldb=ldx, a_bs=0, b_bs=Nk * ldx,
+                       out_op=vT.ptr, oo_bs=d * Np, ldoo=Np, oo_lo=vT.lo, row_bias=bias_ptr)
+        return vT

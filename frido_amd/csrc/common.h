@@ -1,0 +1,68 @@
+// Shared device helpers for libfrido_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "frido_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define FRIDO_WAVE 64
+
+void frido_set_error(const char* fmt, ...);
+int frido_check_launch(const char* what);
+
+#define FRIDO_REQUIRE(cond, msg)                                            \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            frido_set_error("%s: %s (%s)", __func__, msg, #cond);           \
+            return FRIDO_EINVAL;                                            \
+        }                                                                   \
+    } while (0)
+
+// round-to-nearest-even fp32 -> bf16 bits (inputs are finite on this path)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+// split v into hi (bf16) and lo (bf16 of the residual): v ~= hi + lo to ~2^-17 relative
+__device__ __forceinline__ void split_bf16(float v, uint32_t& hi, uint32_t& lo) {
+    hi = f32_to_bf16_bits(v);
+    lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// store up to 4 consecutive operand elements (bf16 hi / optional lo plane)
+__device__ __forceinline__ void store_op4(frido_bf16* op, int64_t lo_off, int nsplit, int64_t idx, const float v[4]) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_bf16(v[i], h[i], l[i]);
+    uint2 ph = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *reinterpret_cast<uint2*>(op + idx) = ph;
+    if (nsplit == 2) {
+        uint2 pl = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        *reinterpret_cast<uint2*>(op + lo_off + idx) = pl;
+    }
+}
+__device__ __forceinline__ void store_op1(frido_bf16* op, int64_t lo_off, int nsplit, int64_t idx, float v) {
+    uint32_t h, l;
+    split_bf16(v, h, l);
+    op[idx] = (frido_bf16)h;
+    if (nsplit == 2) op[lo_off + idx] = (frido_bf16)l;
+}

@@ -1,0 +1,266 @@
+// HBM-bound normalisation / activation kernels: GroupNorm statistics + apply (with SPADE and SiLU),
+// LayerNorm, row softmax, GEGLU.  All read NHWC f32 with 16-byte coalesced accesses and write bf16
+// "operand" tensors (hi plane, plus the residual plane in bf16x3 mode) for the MFMA kernels.
+// Reductions use wave64 shuffles; cross-wave / cross-workgroup combination is in a fixed order
+// (no float atomics) so results are bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics: grid (nsplit_px, B).  Thread t owns float4 column c4 = t % TC of pixel lane
+// t / TC and accumulates {sum, sumsq} over its pixels in registers; LDS holds [PL][C] partials which
+// `groups` threads reduce in double.
+constexpr int GN_MAXC = 4096;
+
+__device__ __forceinline__ float4 load_cat4(const float* x1, int C1, const float* x2, int C2, int64_t pix, int c) {
+    if (c < C1) return *reinterpret_cast<const float4*>(x1 + pix * C1 + c);
+    return *reinterpret_cast<const float4*>(x2 + pix * C2 + (c - C1));
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
+    __shared__ float s_sum[GN_MAXC];
+    __shared__ float s_sq[GN_MAXC];
+    const int C = d.C1 + d.C2, C4 = C >> 2;
+    const int TC = C4 < 256 ? C4 : 256;
+    const int PL = 256 / TC;
+    const int t = threadIdx.x, b = blockIdx.y, sp = blockIdx.x;
+    const int ppx = (d.HW + d.nsplit_px - 1) / d.nsplit_px;
+    const int p0 = sp * ppx, p1 = min(d.HW, p0 + ppx);
+    const int pl = t / TC, tc = t - pl * TC;
+    const int cpg = C / d.groups;
+    // one pass per 256-column chunk (a single pass whenever C <= 1024)
+    double gsum = 0.0, gsq = 0.0;
+    for (int cbase = 0; cbase < C4; cbase += TC) {
+        const int c4 = cbase + tc;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+        if (pl < PL && c4 < C4) {
+            for (int p = p0 + pl; p < p1; p += PL) {
+                const float4 v = load_cat4(d.x1, d.C1, d.x2, d.C2, (int64_t)b * d.HW + p, c4 * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+            }
+        }
+        // combine the PL pixel lanes of each column in a fixed order through LDS
+        for (int l = 0; l < PL; ++l) {
+            if (pl == l && c4 < C4) {
+                float* ps = s_sum + c4 * 4; float* pq = s_sq + c4 * 4;
+                if (l == 0) { ps[0] = s.x; ps[1] = s.y; ps[2] = s.z; ps[3] = s.w; pq[0] = q.x; pq[1] = q.y; pq[2] = q.z; pq[3] = q.w; }
+                else { ps[0] += s.x; ps[1] += s.y; ps[2] += s.z; ps[3] += s.w; pq[0] += q.x; pq[1] += q.y; pq[2] += q.z; pq[3] += q.w; }
+            }
+            __syncthreads();
+        }
+    }
+    if (t < d.groups) {
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { gsum += (double)s_sum[c]; gsq += (double)s_sq[c]; }
+        double* out = d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + t) * 2;
+        out[0] = gsum;
+        out[1] = gsq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm apply: grid (blocks_per_image, B); prologue turns the partials into {mean, rstd}.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = d.C1 + d.C2, C4 = C >> 2;
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int cpg = C / d.groups;
+    if (t < d.groups) {
+        double s = 0.0, q = 0.0;
+        for (int sp = 0; sp < d.nsplit_px; ++sp) {
+            const double* p = d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + t) * 2;
+            s += p[0];
+            q += p[1];
+        }
+        const double n = (double)d.HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[t] = (float)mean;
+        s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)d.HW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        const int64_t pix = (int64_t)b * d.HW + p;
+        const float4 v = load_cat4(d.x1, d.C1, d.x2, d.C2, pix, c);
+        const float xin[4] = {v.x, v.y, v.z, v.w};
+        const float4 w = *reinterpret_cast<const float4*>(d.weight + c);
+        const float4 bi = *reinterpret_cast<const float4*>(d.bias + c);
+        const float ww[4] = {w.x, w.y, w.z, w.w}, bb[4] = {bi.x, bi.y, bi.z, bi.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            y[e] = (xin[e] - s_mean[g]) * s_rstd[g] * ww[e] + bb[e];
+        }
+        const int64_t o = pix * C + c;
+        if (d.gamma) {
+            const float4 ga = *reinterpret_cast<const float4*>(d.gamma + o);
+            const float4 be = *reinterpret_cast<const float4*>(d.beta + o);
+            y[0] = y[0] * (1.f + ga.x) + be.x;
+            y[1] = y[1] * (1.f + ga.y) + be.y;
+            y[2] = y[2] * (1.f + ga.z) + be.z;
+            y[3] = y[3] * (1.f + ga.w) + be.w;
+        }
+        if (d.act == FRIDO_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = silu_f(y[e]);
+        }
+        if (d.out_op) store_op4(d.out_op, d.out_lo, d.nsplit, o, y);
+        if (d.raw_op) store_op4(d.raw_op, d.raw_lo, d.nsplit, o, xin);
+        if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row cached in registers (C <= 1024).
+__global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.rows) return;
+    const float* x = d.x + (int64_t)row * d.C;
+    const int C4 = d.C >> 2;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + i * 64;
+        v[i] = c4 < C4 ? *reinterpret_cast<const float4*>(x + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / d.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + i * 64 < C4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + e * e);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / d.C + d.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < C4) {
+            const float4 w = *reinterpret_cast<const float4*>(d.weight + c4 * 4);
+            const float4 bi = *reinterpret_cast<const float4*>(d.bias + c4 * 4);
+            const float y[4] = {(v[i].x - mean) * rstd * w.x + bi.x, (v[i].y - mean) * rstd * w.y + bi.y,
+                                (v[i].z - mean) * rstd * w.z + bi.z, (v[i].w - mean) * rstd * w.w + bi.w};
+            store_op4(d.out_op, d.out_lo, d.nsplit, (int64_t)row * d.C + c4 * 4, y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax: one wave per row, N <= 4096 (64 values per lane in registers), zero-padded output.
+__global__ __launch_bounds__(256) void softmax_kernel(const FridoSoftmax d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.rows) return;
+    const float* x = d.x + (int64_t)row * d.ld;
+    constexpr int MAXV = 64;
+    float v[MAXV];
+    const int nv = (d.N + 63) >> 6;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < nv) {
+            const int c = lane + i * 64;
+            v[i] = c < d.N ? x[c] : -3.0e38f;
+            mx = fmaxf(mx, v[i]);
+        }
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < nv) {
+            const int c = lane + i * 64;
+            v[i] = c < d.N ? __expf(v[i] - mx) : 0.f;
+            s += v[i];
+        }
+    }
+    const float inv = 1.0f / wave_sum(s);
+    frido_bf16* o = d.out_op + (int64_t)row * d.Npad;
+    const int npv = (d.Npad + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < npv) {
+            const int c = lane + i * 64;
+            if (c < d.Npad) store_op1(o, d.out_lo, d.nsplit, c, i < nv ? v[i] * inv : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geglu_kernel(const FridoGeglu d) {
+    const int H4 = d.H >> 2;
+    const int64_t total = (int64_t)d.rows * H4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / H4;
+        const int c = (int)(i - r * H4) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(d.x + r * 2 * d.H + c);
+        const float4 g = *reinterpret_cast<const float4*>(d.x + r * 2 * d.H + d.H + c);
+        const float aa[4] = {a.x, a.y, a.z, a.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = aa[e] * (0.5f * gg[e] * (1.0f + erff(gg[e] * 0.70710678118654752f)));
+        store_op4(d.out_op, d.out_lo, d.nsplit, r * d.H + c, y);
+    }
+}
+
+inline int grid_for(int64_t work_items, int cap = 4096) {
+    int64_t b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int frido_gn_stats(const FridoGnStats* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->x1 && d->partials, "null pointer");
+    const int C = d->C1 + d->C2;
+    FRIDO_REQUIRE(d->groups > 0 && d->groups <= 64 && C % d->groups == 0, "channels not divisible by groups");
+    FRIDO_REQUIRE((d->C1 & 3) == 0 && (d->C2 & 3) == 0 && C <= GN_MAXC, "channel counts must be multiples of 4, <= 4096");
+    FRIDO_REQUIRE(d->B > 0 && d->HW > 0 && d->nsplit_px > 0, "empty");
+    FRIDO_REQUIRE(d->C2 == 0 || d->x2, "x2 missing");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(d->nsplit_px, d->B), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("gn_stats");
+}
+
+extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->x1 && d->partials && d->weight && d->bias, "null pointer");
+    const int C = d->C1 + d->C2;
+    FRIDO_REQUIRE(d->groups > 0 && d->groups <= 64 && C % d->groups == 0, "channels not divisible by groups");
+    FRIDO_REQUIRE((d->C1 & 3) == 0 && (d->C2 & 3) == 0, "channel counts must be multiples of 4");
+    FRIDO_REQUIRE(d->out_op || d->out_f32, "no output");
+    FRIDO_REQUIRE((d->gamma == nullptr) == (d->beta == nullptr), "gamma/beta must come together");
+    const int64_t per_img = (int64_t)d->HW * (C >> 2);
+    int gx = grid_for(per_img, 2048 / (d->B < 2048 ? d->B : 2048) + 8);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("gn_apply");
+}
+
+extern "C" int frido_layernorm(const FridoLayerNorm* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->x && d->weight && d->bias && d->out_op, "null pointer");
+    FRIDO_REQUIRE((d->C & 3) == 0 && d->C <= 1024 && d->rows > 0, "C must be a multiple of 4, <= 1024");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((d->rows + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("layernorm");
+}
+
+extern "C" int frido_softmax(const FridoSoftmax* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->x && d->out_op, "null pointer");
+    FRIDO_REQUIRE(d->N > 0 && d->N <= 4096 && d->Npad >= d->N && d->Npad <= 4096 && d->rows > 0, "N must be in [1, 4096]");
+    hipLaunchKernelGGL(softmax_kernel, dim3((d->rows + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("softmax");
+}
+
+extern "C" int frido_geglu(const FridoGeglu* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->x && d->out_op, "null pointer");
+    FRIDO_REQUIRE((d->H & 3) == 0 && d->rows > 0, "H must be a multiple of 4");
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((int64_t)d->rows * (d->H >> 2))), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("geglu");
+}

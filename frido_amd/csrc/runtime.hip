@@ -1,0 +1,197 @@
+// Native executor of libfrido_hip: runs / captures "programs" (arrays of tagged op descriptors) on a
+// HIP stream, owns the hipGraph objects of the captured per-step bodies, HIP-event timing on the
+// launch stream, and error reporting.  One program = one U-Net forward + sampler update (or the
+// VQGAN decode); the Python host builds it once per (model, batch, stage) and replays it.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void frido_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int frido_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        frido_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return FRIDO_EHIP;
+    }
+    return FRIDO_OK;
+}
+
+namespace {
+
+int run_one(const FridoOp& op, frido_stream_t s) {
+    switch (op.kind) {
+        case FRIDO_OP_GEMM: return frido_gemm(&op.u.gemm, s);
+        case FRIDO_OP_GN_STATS: return frido_gn_stats(&op.u.gn_stats, s);
+        case FRIDO_OP_GN_APPLY: return frido_gn_apply(&op.u.gn_apply, s);
+        case FRIDO_OP_LAYERNORM: return frido_layernorm(&op.u.layernorm, s);
+        case FRIDO_OP_SOFTMAX: return frido_softmax(&op.u.softmax, s);
+        case FRIDO_OP_GEGLU: return frido_geglu(&op.u.geglu, s);
+        case FRIDO_OP_PACK: return frido_pack(&op.u.pack, s);
+        case FRIDO_OP_RELAYOUT: return frido_relayout(&op.u.relayout, s);
+        case FRIDO_OP_VQ: return frido_vq(&op.u.vq, s);
+        case FRIDO_OP_SAMPLER_STEP: return frido_sampler_step(&op.u.sampler_step, s);
+        case FRIDO_OP_HANDOFF: return frido_handoff(&op.u.handoff, s);
+        case FRIDO_OP_RANDN: return frido_randn(&op.u.randn, s);
+        case FRIDO_OP_STEP_ADD: return frido_step_add(&op.u.step_add, s);
+        case FRIDO_OP_FILL: return frido_fill(&op.u.fill, s);
+        default:
+            frido_set_error("frido_run: unknown op kind %d", op.kind);
+            return FRIDO_EINVAL;
+    }
+}
+
+struct Graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace
+
+extern "C" int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s) {
+    if (!ops || n < 0) {
+        frido_set_error("frido_run: bad arguments");
+        return FRIDO_EINVAL;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        int rc = run_one(ops[i], s);
+        if (rc != FRIDO_OK) {
+            char tmp[400];
+            snprintf(tmp, sizeof(tmp), "%s", g_err);
+            frido_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
+            return rc;
+        }
+    }
+    return FRIDO_OK;
+}
+
+extern "C" int frido_graph_capture(const FridoOp* ops, int32_t n, frido_stream_t s, void** out) {
+    if (!ops || n <= 0 || !out) {
+        frido_set_error("frido_graph_capture: bad arguments");
+        return FRIDO_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)s;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        frido_set_error("hipStreamBeginCapture: %s", hipGetErrorString(e));
+        return FRIDO_EHIP;
+    }
+    int rc = frido_run(ops, n, s);
+    Graph* g = new Graph();
+    e = hipStreamEndCapture(st, &g->graph);
+    if (rc != FRIDO_OK || e != hipSuccess) {
+        if (e != hipSuccess) frido_set_error("hipStreamEndCapture: %s", hipGetErrorString(e));
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return rc != FRIDO_OK ? rc : FRIDO_EHIP;
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        frido_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        return FRIDO_EHIP;
+    }
+    *out = g;
+    return FRIDO_OK;
+}
+
+extern "C" int frido_graph_launch(void* graph, frido_stream_t s) {
+    Graph* g = (Graph*)graph;
+    if (!g || !g->exec) {
+        frido_set_error("frido_graph_launch: null graph");
+        return FRIDO_EINVAL;
+    }
+    hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)s);
+    if (e != hipSuccess) {
+        frido_set_error("hipGraphLaunch: %s", hipGetErrorString(e));
+        return FRIDO_EHIP;
+    }
+    return FRIDO_OK;
+}
+
+extern "C" int frido_graph_destroy(void* graph) {
+    Graph* g = (Graph*)graph;
+    if (!g) return FRIDO_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return FRIDO_OK;
+}
+
+extern "C" int frido_event_create(void** ev) {
+    hipEvent_t e;
+    if (!ev || hipEventCreate(&e) != hipSuccess) {
+        frido_set_error("hipEventCreate failed");
+        return FRIDO_EHIP;
+    }
+    *ev = (void*)e;
+    return FRIDO_OK;
+}
+extern "C" int frido_event_record(void* ev, frido_stream_t s) {
+    if (hipEventRecord((hipEvent_t)ev, (hipStream_t)s) != hipSuccess) {
+        frido_set_error("hipEventRecord failed");
+        return FRIDO_EHIP;
+    }
+    return FRIDO_OK;
+}
+extern "C" int frido_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!ms) return FRIDO_EINVAL;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess || hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {
+        frido_set_error("hipEventElapsedTime failed");
+        return FRIDO_EHIP;
+    }
+    return FRIDO_OK;
+}
+extern "C" int frido_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+    return FRIDO_OK;
+}
+
+extern "C" int frido_abi_version(void) { return 1; }
+extern "C" int frido_sizeof_op(void) { return (int)sizeof(FridoOp); }
+extern "C" int frido_sizeof_desc(int32_t kind) {
+    switch (kind) {
+        case FRIDO_OP_GEMM: return sizeof(FridoGemm);
+        case FRIDO_OP_GN_STATS: return sizeof(FridoGnStats);
+        case FRIDO_OP_GN_APPLY: return sizeof(FridoGnApply);
+        case FRIDO_OP_LAYERNORM: return sizeof(FridoLayerNorm);
+        case FRIDO_OP_SOFTMAX: return sizeof(FridoSoftmax);
+        case FRIDO_OP_GEGLU: return sizeof(FridoGeglu);
+        case FRIDO_OP_PACK: return sizeof(FridoPack);
+        case FRIDO_OP_RELAYOUT: return sizeof(FridoRelayout);
+        case FRIDO_OP_VQ: return sizeof(FridoVq);
+        case FRIDO_OP_SAMPLER_STEP: return sizeof(FridoSamplerStep);
+        case FRIDO_OP_HANDOFF: return sizeof(FridoHandoff);
+        case FRIDO_OP_RANDN: return sizeof(FridoRandn);
+        case FRIDO_OP_STEP_ADD: return sizeof(FridoStepAdd);
+        case FRIDO_OP_FILL: return sizeof(FridoFill);
+        default: return -1;
+    }
+}
+extern "C" const char* frido_last_error(void) { return g_err; }
+
+extern "C" int frido_device_info(int32_t* cu_count, int32_t* is_gfx950, int64_t* hbm_bytes) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        frido_set_error("no HIP device");
+        return FRIDO_EHIP;
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (is_gfx950) *is_gfx950 = (strncmp(p.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return FRIDO_OK;
+}

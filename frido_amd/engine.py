@@ -1,0 +1,227 @@
+"""Host side of the HIP engine: device buffers (torch tensors are used purely as HBM allocations),
+weight packing into MFMA operand layouts, and a program builder that emits FridoOp descriptors for
+the native executor (frido_run / frido_graph_capture in libfrido_hip.so).
+
+Nothing here computes on the CPU and nothing falls back to torch ops: every tensor that reaches the
+model output is produced by a kernel of libfrido_hip.so.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BF16X3 = 2   # nsplit: hi + residual plane, 3 MFMAs per product (≈ fp32 accuracy)
+BF16 = 1     # nsplit: plain bf16 operands
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Operand:
+    """bf16 operand matrix [rows][K] (K contiguous) with `nsplit` planes; plane p starts p*lo elements in."""
+
+    def __init__(self, rows, K, nsplit, device, zero=False, batch=1):
+        self.rows, self.K, self.nsplit, self.batch = rows, K, nsplit, batch
+        n = batch * rows * K
+        self.lo = rup(n, 8)
+        alloc = torch.zeros if zero else torch.empty
+        self.t = alloc((nsplit, self.lo), dtype=torch.bfloat16, device=device)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    def nbytes(self):
+        return self.t.numel() * 2
+
+    def to_f32(self):
+        """Debug helper: hi (+ lo) planes as an f32 tensor [batch*rows, K]."""
+        n = self.batch * self.rows * self.K
+        v = self.t[0, :n].float()
+        if self.nsplit == 2:
+            v = v + self.t[1, :n].float()
+        return v.view(self.batch * self.rows, self.K)
+
+
+def pack_matrix(w2d, nsplit, kpad=32):
+    """f32 [N][K] on device -> Operand with K zero-padded to a multiple of `kpad` (torch's RNE casts)."""
+    N, K = w2d.shape
+    Kp = rup(K, kpad)
+    op = Operand(N, Kp, nsplit, w2d.device, zero=True)
+    w = w2d.float()
+    hi = w.to(torch.bfloat16)
+    view = op.t[0, :N * Kp].view(N, Kp)
+    view[:, :K] = hi
+    if nsplit == 2:
+        op.t[1, :N * Kp].view(N, Kp)[:, :K] = (w - hi.float()).to(torch.bfloat16)
+    return op
+
+
+def pack_conv_weight(w4d, nsplit):
+    """(Cout, Cin, kh, kw) -> [Cout][kh*kw*Cin_pad] with k = (ky*kw + kx)*Cin_pad + c."""
+    co, ci, kh, kw = w4d.shape
+    cp = rup(ci, 32)
+    w = torch.zeros((co, kh, kw, cp), dtype=torch.float32, device=w4d.device)
+    w[..., :ci] = w4d.permute(0, 2, 3, 1)
+    return pack_matrix(w.reshape(co, kh * kw * cp), nsplit), cp
+
+
+class Graph:
+    def __init__(self, handle, keep):
+        self.handle, self.keep = handle, keep
+
+    def launch(self, stream):
+        _lib.check(_lib.lib().frido_graph_launch(self.handle, stream), "frido_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().frido_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Pool:
+    """Plan-time buffer pool: ops of one program run in order on one stream, so a buffer can be handed
+    out again as soon as the builder has emitted its last reader."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free_bufs = {}
+        self.total = 0
+
+    def alloc(self, nbytes):
+        nbytes = rup(max(nbytes, 16), 256)
+        lst = self.free_bufs.get(nbytes)
+        if lst:
+            return lst.pop()
+        self.total += nbytes
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def release(self, buf):
+        self.free_bufs.setdefault(buf.numel(), []).append(buf)
+
+
+class F32:
+    """f32 activation [rows][C] living in a pooled buffer."""
+
+    def __init__(self, pool, rows, C):
+        self.rows, self.C, self.pool = rows, C, pool
+        self.buf = pool.alloc(rows * C * 4)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def view(self):
+        return self.buf[: self.rows * self.C * 4].view(torch.float32).view(self.rows, self.C)
+
+    def free(self):
+        if self.buf is not None:
+            self.pool.release(self.buf)
+            self.buf = None
+
+
+class POperand:
+    """Pooled operand (activation) [rows][K] with nsplit planes."""
+
+    def __init__(self, pool, rows, K, nsplit, batch=1):
+        self.rows, self.K, self.nsplit, self.batch, self.pool = rows, K, nsplit, batch, pool
+        self.lo = rup(batch * rows * K, 8)
+        self.buf = pool.alloc(nsplit * self.lo * 2)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def to_f32(self):
+        n = self.batch * self.rows * self.K
+        t = self.buf[: self.nsplit * self.lo * 2].view(torch.bfloat16).view(self.nsplit, self.lo)
+        v = t[0, :n].float()
+        if self.nsplit == 2:
+            v = v + t[1, :n].float()
+        return v.view(self.batch * self.rows, self.K)
+
+    def free(self):
+        if self.buf is not None:
+            self.pool.release(self.buf)
+            self.buf = None
+
+
+class Prog:
+    """A list of ops + the tensors they reference (kept alive)."""
+
+    def __init__(self, device, nsplit):
+        self.device, self.nsplit = device, nsplit
+        self.ops = []
+        self.keep = []
+        self._packed = None
+        self.flops = 0
+
+    # ---- emission helpers -------------------------------------------------------------------
+    def emit(self, kind, **kw):
+        self.ops.append(_lib.make_op(kind, **kw))
+        self._packed = None
+
+    def gemm(self, M, N, K, A, B, *, batch=1, lda=None, ldb=None, a_bs=0, b_bs=0, a_lo=None, b_lo=None,
+             bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
+             residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
+             oo_lo=0, tile=0, conv=None, row_bias=None):
+        """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
+        ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
+        bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
+        kw = dict(M=M, N=N, K=K, batch=batch, nsplit=self.nsplit, A=ap, a_lo=alo if a_lo is None else a_lo,
+                  a_bs=a_bs, lda=lda if lda is not None else K, B=bp, b_lo=blo if b_lo is None else b_lo,
+                  b_bs=b_bs, ldb=ldb if ldb is not None else K, alpha=alpha, act=act, tile=tile)
+        if conv:
+            kw.update(conv=1, **conv)
+        if bias is not None:
+            kw["bias"] = bias
+        if row_bias is not None:
+            kw["row_bias"] = row_bias
+        if rowvec is not None:
+            kw.update(rowvec=rowvec, rows_per_vec=rows_per_vec, ldv=ldv)
+            if rowvec_step is not None:
+                kw["rowvec_step"] = rowvec_step
+        if residual is not None:
+            kw.update(residual=residual, res_bs=res_bs, ldr=ldr)
+        if out_f32 is not None:
+            kw.update(out_f32=out_f32, of_bs=of_bs, ldo=ldo)
+        if out_op is not None:
+            kw.update(out_op=out_op, oo_bs=oo_bs, ldoo=ldoo, oo_lo=oo_lo)
+        self.emit("FRIDO_OP_GEMM", **kw)
+        self.flops += 2 * M * N * K * batch * (3 if self.nsplit == 2 else 1)
+
+    # ---- execution ---------------------------------------------------------------------------
+    def packed(self):
+        if self._packed is None:
+            self._packed = _lib.pack_ops(self.ops)
+        return self._packed
+
+    def run(self, stream):
+        arr = self.packed()
+        _lib.check(_lib.lib().frido_run(C.addressof(arr), len(self.ops), stream), "frido_run")
+
+    def capture(self, stream):
+        arr = self.packed()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().frido_graph_capture(C.addressof(arr), len(self.ops), stream, C.byref(h)),
+                   "frido_graph_capture")
+        return Graph(h, (arr, self))
+
+
+def current_stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.FridoHipError(
+            f"the Frido hot path runs only on an MI355X HIP device (got device '{device}'); there is no CPU path")
+    _lib.lib()
+    return device

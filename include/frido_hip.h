@@ -1,0 +1,248 @@
+/*
+ * frido_hip.h — C ABI of libfrido_hip.so, the MI355X (gfx950) hot path of the Frido sampler.
+ *
+ * The reference (davidhalladay/Frido) is 100 % Python/PyTorch and has no FFI of its own
+ * (SURVEY.md §2b, §8b): every device op there is an ATen call made from the files cited below.
+ * Each entry point here replaces one cluster of those call sites.  Conventions:
+ *   - extern "C", plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     owned by the caller (PyTorch-ROCm tensors, or hipMalloc from C), 16-byte aligned;
+ *   - every launcher returns 0 on success, a negative FRIDO_E* code on bad arguments or a HIP
+ *     error (never throws, never exits); kernels are enqueued on the caller's hipStream_t and
+ *     are hipGraph-capturable (no allocation, no synchronisation inside);
+ *   - activations are NHWC fp32 ("f32") or NHWC bf16 "operand" tensors.  An operand tensor is
+ *     a bf16 matrix [rows][K] with K contiguous; in bf16x3 mode (nsplit == 2) a second bf16
+ *     plane holding the rounding residual lives `lo` elements after the first, and products are
+ *     accumulated as hi*hi + hi*lo + lo*hi in fp32 on the MFMA pipe (≈2^-17 relative error).
+ */
+#ifndef FRIDO_HIP_H
+#define FRIDO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* frido_stream_t;   /* a hipStream_t */
+typedef uint16_t frido_bf16;
+
+#define FRIDO_OK 0
+#define FRIDO_EINVAL (-1)
+#define FRIDO_EHIP (-2)
+#define FRIDO_EUNSUPPORTED (-3)
+
+enum { FRIDO_ACT_NONE = 0, FRIDO_ACT_RELU = 1, FRIDO_ACT_SILU = 2 };
+
+/* ------------------------------------------------------------------------------------------
+ * frido_gemm — implicit-GEMM on the MFMA pipe:  for z < batch:
+ *     C[z][m][n] = act(alpha * sum_k A[z][m][k] * B[z][n][k] + bias[n] + rowvec[r(m)][n]) + residual[z][m][n]
+ * Dense mode (conv == 0): A is an operand matrix [M][K] (lda).  Replaces nn.Linear / 1x1 conv /
+ *   einsum call sites: frido/modules/attention.py:161-192 (to_q/k/v/out, QK^T, PV), :47-64 (FF),
+ *   :265-280 (proj_in/out); pyunet.py:248 (skip_connection), :225-231 (emb_layers), :560-565
+ *   (time_embed); taming/modules/diffusionmodules/model.py:148-192 (AttnBlock q/k/v/proj, bmm);
+ *   taming/models/msvqgan.py:75 (post_quant_conv).
+ * Conv mode (conv == 1): A is an NHWC operand image [Bimg][Hs][Ws][Cin]; row m = (b, oy, ox),
+ *   k = (ky*kw + kx)*Cin + c; logical input pixel (oy*stride+ky-pad, ox*stride+kx-pad) inside
+ *   [0,Hl)x[0,Wl) maps to source pixel ((iy >> up_shift) << dn_shift, ...), zero outside.
+ *   Replaces F.conv2d call sites: pyunet.py:208-239 (ResBlock 3x3), :110,119-121 (Upsample =
+ *   up_shift 1), :152-156 (Downsample, stride 2 pad 1), :575-600,797-803 (heads);
+ *   spade_norm.py:52-58 (SPADE convs on the nearest-resized map = dn_shift);
+ *   taming/.../model.py:38-75 (Up/Downsample, asymmetric pad = pad 0 + bounds), :85-112.
+ * K must be a multiple of 32 (operands are zero-padded by their producers); M, N arbitrary.
+ */
+typedef struct FridoGemm {
+    int32_t M, N, K, batch;
+    int32_t nsplit;             /* 1 = bf16, 2 = bf16x3 */
+    int32_t conv;               /* 0 dense, 1 conv */
+    const frido_bf16* A; int64_t a_lo; int64_t a_bs; int32_t lda;
+    int32_t Hs, Ws, Cin;        /* conv: source image dims, Cin % 32 == 0 */
+    int32_t Hl, Wl;             /* conv: logical (resized) input dims */
+    int32_t Ho, Wo;             /* conv: output dims; M = Bimg*Ho*Wo */
+    int32_t kh, kw, stride, pad, up_shift, dn_shift;
+    const frido_bf16* B; int64_t b_lo; int64_t b_bs; int32_t ldb;
+    float alpha;
+    const float* bias;          /* [N] per output column */
+    const float* row_bias;      /* [M] per output row (transposed projections) */
+    const float* rowvec; int32_t rows_per_vec; int32_t ldv;   /* row index m / rows_per_vec + *rowvec_step */
+    const int32_t* rowvec_step;
+    int32_t act;
+    const float* residual; int64_t res_bs; int32_t ldr;
+    float* out_f32; int64_t of_bs; int32_t ldo;
+    frido_bf16* out_op; int64_t oo_lo; int64_t oo_bs; int32_t ldoo;
+    int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64 */
+} FridoGemm;
+
+/* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two
+ * NHWC f32 tensors: nn.GroupNorm call sites util.py:214-216 (eps 1e-5), attention.py:76-77 and
+ * taming/.../model.py:34-35 (eps 1e-6); the concat is pyunet.py:939.  Writes per-(b, split, group)
+ * partial {sum, sumsq} as doubles: partials[b][s][g][2]; the consumer combines them. */
+typedef struct FridoGnStats {
+    const float* x1; int32_t C1; const float* x2; int32_t C2;
+    int32_t B, HW, groups, nsplit_px;
+    double* partials;
+} FridoGnStats;
+
+/* GroupNorm apply (+ SPADE modulation + SiLU) -> operand tensor.
+ *   y = (x - mean) * rstd * weight[c] + bias[c];  if gamma: y = y * (1 + gamma) + beta  (spade_norm.py:60)
+ *   if act == SILU: y = y * sigmoid(y)   (pyunet.py:210,234; taming model.py:28-31)
+ * Optionally also writes the un-normalised x as an operand (`raw_op`, input of a 1x1 skip conv,
+ * pyunet.py:248,300) and/or y as f32 (`out_f32`). */
+typedef struct FridoGnApply {
+    const float* x1; int32_t C1; const float* x2; int32_t C2;
+    int32_t B, HW, groups, nsplit_px;
+    const double* partials; float eps;
+    const float* weight; const float* bias;
+    const float* gamma; const float* beta;
+    int32_t act; int32_t nsplit;
+    frido_bf16* out_op; int64_t out_lo;
+    frido_bf16* raw_op; int64_t raw_lo;
+    float* out_f32;
+} FridoGnApply;
+
+/* LayerNorm over the last dim (eps 1e-5, affine): attention.py:203-205 -> operand tensor. */
+typedef struct FridoLayerNorm {
+    const float* x; int32_t rows, C; float eps;
+    const float* weight; const float* bias;
+    int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
+} FridoLayerNorm;
+
+/* Row softmax (attention.py:188, taming model.py:181): x[rows][N] f32 (ld) -> operand [rows][Npad]
+ * with columns >= N written as zero. */
+typedef struct FridoSoftmax {
+    const float* x; int32_t rows, N, ld, Npad;
+    int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
+} FridoSoftmax;
+
+/* GEGLU gate (attention.py:42-44): x[rows][2H] f32 -> operand [rows][H] = x[:, :H] * gelu_erf(x[:, H:]). */
+typedef struct FridoGeglu {
+    const float* x; int32_t rows, H;
+    int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
+} FridoGeglu;
+
+/* f32 -> operand conversion with channel slice and zero padding.  src is NCHW (nchw = 1, channel
+ * stride HW) or NHWC/row-major (nchw = 0) with Csrc channels; channels [c0, c0+Cuse) go to operand
+ * columns [0, Cuse), columns up to Cpad are zero.  `scale` multiplies the value (1.0 = exact copy). */
+typedef struct FridoPack {
+    const float* src; int32_t B, HW, Csrc, c0, Cuse, Cpad, nchw;
+    float scale;
+    int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
+} FridoPack;
+
+/* f32 layout change: NHWC [B][HW][Csrc] columns [c0, c0+Cuse) -> NCHW dst[B][Cdst][HW] at channel d0,
+ * or the reverse direction (to_nchw = 0: NCHW src -> NHWC dst). */
+typedef struct FridoRelayout {
+    const float* src; float* dst;
+    int32_t B, HW, Csrc, c0, Cuse, Cdst, d0, to_nchw;
+} FridoRelayout;
+
+/* VectorQuantizer2 lookup (taming/modules/vqvae/quantize.py:272-294) fused with the per-scale
+ * 1/scale_factor of decode_first_stage (frido.py:832-838): z = x[..., c0:c0+e] * inv_scale;
+ * idx = argmin_j (|z|^2 + |e_j|^2 - 2 z.e_j) (lowest index on ties); writes z + (e_idx - z) into
+ * zq[..., q0:q0+e] (NHWC f32, Cq channels) and idx (int64). */
+typedef struct FridoVq {
+    const float* x; int32_t npix, Cx, c0, e;
+    float inv_scale;
+    const float* codebook; int32_t n_codes;
+    float* zq; int32_t Cq, q0;
+    int64_t* idx;
+} FridoVq;
+
+/* One DDIM / PLMS state update (ddim.py:232-273, plms.py:247-303) on the NHWC f32 latent state
+ * x[B][HW][Cx] for the active stage channels [start, start+nch):
+ *   e      = CFG mix e_u + s (e_c - e_u) if eps_uncond else eps_cond         (ddim.py:211-226)
+ *   PLMS:  e = sum_k ab[k] * hist[k] (Adams-Bashforth coefficients from coef row) when hist != null
+ *   x0     = (x - sqrt(1-a_t) e) / sqrt(a_t);  x' = sqrt(a_prev) x0 + sqrt(1-a_prev-sigma^2) e + sigma*noise*T
+ * Coefficients are read from coef[*step][8] = {a_t, a_prev, sigma, sqrt(1-a_t), ab0..ab3};
+ * noise is either a tape (noise[*step * noise_stride + ...], NHWC [B][HW][nch_noise] with the
+ * active channels at `noise_c0`) or Philox4x32-10 keyed by (seed, global sample index, *step).
+ * Frozen channels [0,start) are passed through (x0 = x, x' = x0). */
+typedef struct FridoSamplerStep {
+    float* x; int32_t B, HW, Cx, start, nch;
+    const float* eps_cond; const float* eps_uncond; float cfg_scale;   /* [B*HW][nch] */
+    float* eps_out;              /* optional: the (CFG-mixed) eps, [B*HW][nch] (PLMS history slot) */
+    const float* hist1; const float* hist2; const float* hist3;   /* PLMS older eps or null */
+    const float* coef; const int32_t* step; int32_t coef_row_offset;
+    const float* noise; int64_t noise_stride; int32_t noise_C, noise_c0;
+    uint64_t seed; int64_t sample0; int32_t rng_stream;
+    float temperature;
+    float* x_out;                /* where x' goes (may alias x) */
+    float* pred_x0;              /* optional [B][HW][Cx] */
+    int32_t write_x;             /* 0: only eps_out/pred_x0 */
+} FridoSamplerStep;
+
+/* Stage hand-off (ddim.py:177-185): channels [c0,c1) of x[B][H][W][Cx] replaced by their
+ * 2^levels x 2^levels block mean (avg_pool2d applied `levels` times, then nearest expand). */
+typedef struct FridoHandoff {
+    float* x; int32_t B, H, W, Cx, c0, c1, levels;
+} FridoHandoff;
+
+/* Gaussian fill: dst[i] ~ N(0,1), Philox keyed by (seed, sample index = sample0 + i / per_sample, stream). */
+typedef struct FridoRandn {
+    float* dst; int64_t n; int64_t per_sample; uint64_t seed; int64_t sample0; int32_t rng_stream;
+} FridoRandn;
+
+/* step counter update: *step += delta (one thread). */
+typedef struct FridoStepAdd { int32_t* step; int32_t delta; } FridoStepAdd;
+
+/* fill a device buffer with a 32-bit pattern. */
+typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill;
+
+enum FridoOpKind {
+    FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
+    FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP__COUNT
+};
+
+/* A program is an array of tagged ops executed in order on one stream by the native executor. */
+typedef struct FridoOp {
+    int32_t kind; int32_t _pad;
+    union {
+        FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
+        FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
+        FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
+        FridoFill fill;
+        char _size[320];
+    } u;
+} FridoOp;
+
+/* ---- single-op launchers ---- */
+int frido_gemm(const FridoGemm* d, frido_stream_t s);
+int frido_gn_stats(const FridoGnStats* d, frido_stream_t s);
+int frido_gn_apply(const FridoGnApply* d, frido_stream_t s);
+int frido_layernorm(const FridoLayerNorm* d, frido_stream_t s);
+int frido_softmax(const FridoSoftmax* d, frido_stream_t s);
+int frido_geglu(const FridoGeglu* d, frido_stream_t s);
+int frido_pack(const FridoPack* d, frido_stream_t s);
+int frido_relayout(const FridoRelayout* d, frido_stream_t s);
+int frido_vq(const FridoVq* d, frido_stream_t s);
+int frido_sampler_step(const FridoSamplerStep* d, frido_stream_t s);
+int frido_handoff(const FridoHandoff* d, frido_stream_t s);
+int frido_randn(const FridoRandn* d, frido_stream_t s);
+int frido_step_add(const FridoStepAdd* d, frido_stream_t s);
+int frido_fill(const FridoFill* d, frido_stream_t s);
+
+/* ---- native executor: run / capture a whole program ---- */
+int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);
+/* Capture `ops` into a hipGraph on stream `s` (which must be a non-default stream) and
+ * instantiate it.  Returns an opaque handle in *out. */
+int frido_graph_capture(const FridoOp* ops, int32_t n, frido_stream_t s, void** out);
+int frido_graph_launch(void* graph, frido_stream_t s);
+int frido_graph_destroy(void* graph);
+
+/* ---- timing on the launch stream (HIP events) ---- */
+int frido_event_create(void** ev);
+int frido_event_record(void* ev, frido_stream_t s);
+int frido_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int frido_event_destroy(void* ev);
+
+/* ---- introspection ---- */
+int frido_abi_version(void);
+int frido_sizeof_op(void);             /* sizeof(FridoOp): checked by the ctypes mirror */
+int frido_sizeof_desc(int32_t kind);   /* sizeof of the descriptor struct of that op kind */
+const char* frido_last_error(void);
+int frido_device_info(int32_t* cu_count, int32_t* gcn_arch_is_gfx950, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRIDO_HIP_H */
