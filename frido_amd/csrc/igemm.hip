@@ -210,17 +210,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const FridoGemm d) {
 }
 
 template <int BM, int BN, int NS, bool CONV>
+int set_attr() {
+    constexpr int smem = 2 * NS * (BM + BN) * 64;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        frido_set_error("igemm: cannot set dynamic LDS size %d", smem);
+        return FRIDO_EHIP;
+    }
+    return FRIDO_OK;
+}
+
+template <int BM, int BN, int NS, bool CONV>
 int launch(const FridoGemm& d, hipStream_t s) {
     constexpr int smem = 2 * NS * (BM + BN) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
-            frido_set_error("igemm: cannot set dynamic LDS size %d", smem);
-            return FRIDO_EHIP;
-        }
-        attr_set = true;
-    }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV>), dim3(tiles, d.batch), dim3(256), smem, s, d);
     return frido_check_launch("igemm");
@@ -247,6 +249,15 @@ int pick_tile(const FridoGemm& d) {
 }
 
 }  // namespace
+
+int frido_igemm_init() {
+    int rc = 0;
+    rc |= set_attr<128, 128, 1, true>() | set_attr<128, 192, 1, true>() | set_attr<64, 64, 1, true>();
+    rc |= set_attr<128, 128, 1, false>() | set_attr<128, 192, 1, false>() | set_attr<64, 64, 1, false>();
+    rc |= set_attr<128, 128, 2, true>() | set_attr<128, 192, 2, true>() | set_attr<64, 64, 2, true>();
+    rc |= set_attr<128, 128, 2, false>() | set_attr<128, 192, 2, false>() | set_attr<64, 64, 2, false>();
+    return rc ? FRIDO_EHIP : FRIDO_OK;
+}
 
 extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     FRIDO_REQUIRE(dp != nullptr, "null descriptor");

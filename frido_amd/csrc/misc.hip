@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const FridoSamplerSte
     const float ab0 = cf[4], ab1 = cf[5], ab2 = cf[6], ab3 = cf[7], den = cf[8];
     const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev);
     const float dir_c = sqrtf(__fsub_rn(__fsub_rn(1.0f, a_prev), __fmul_rn(sigma, sigma)));
+    const uint64_t seed = d.rng_dev ? (uint64_t)d.rng_dev[0] : d.seed;
+    const int64_t sample0 = d.rng_dev ? d.rng_dev[1] : d.sample0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / d.HW, p = i - b * d.HW;
         float nz[12];
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const FridoSamplerSte
             } else {
                 const int ngrp = (d.nch + 3) >> 2;
                 for (int g = 0; g < ngrp; ++g)
-                    randn4(d.seed, d.sample0 + b, (uint32_t)(step + d.coef_row_offset) + 1u, (uint32_t)d.rng_stream,
+                    randn4(seed, sample0 + b, (uint32_t)(step + d.coef_row_offset) + 1u, (uint32_t)d.rng_stream,
                            (uint32_t)(p * ngrp + g), nz + g * 4);
             }
         } else {
@@ -231,6 +233,20 @@ __global__ __launch_bounds__(256) void handoff_kernel(const FridoHandoff d) {
     }
 }
 
+__global__ __launch_bounds__(256) void time_emb_kernel(const FridoTimeEmb d) {
+    const int half = d.dim / 2;
+    const int total = d.n * half;
+    const float neg_log = -logf(d.max_period);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / half, k = i - r * half;
+        const float f = expf(__fdiv_rn(__fmul_rn(neg_log, (float)k), (float)half));
+        const float a = __fmul_rn((float)d.t[r], f);
+        d.out[(int64_t)r * d.dim + k] = cosf(a);
+        d.out[(int64_t)r * d.dim + half + k] = sinf(a);
+        if ((d.dim & 1) && k == 0) d.out[(int64_t)r * d.dim + d.dim - 1] = 0.f;
+    }
+}
+
 __global__ void step_add_kernel(const FridoStepAdd d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *d.step += d.delta;
 }
@@ -291,6 +307,12 @@ extern "C" int frido_step_add(const FridoStepAdd* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->step, "null pointer");
     hipLaunchKernelGGL(step_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, *d);
     return frido_check_launch("step_add");
+}
+
+extern "C" int frido_time_emb(const FridoTimeEmb* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->t && d->out && d->n > 0 && d->dim >= 2, "bad arguments");
+    hipLaunchKernelGGL(time_emb_kernel, dim3(grid_for((int64_t)d->n * (d->dim / 2))), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("time_emb");
 }
 
 extern "C" int frido_fill(const FridoFill* d, frido_stream_t s) {

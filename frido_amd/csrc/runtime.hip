@@ -47,6 +47,7 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_RANDN: return frido_randn(&op.u.randn, s);
         case FRIDO_OP_STEP_ADD: return frido_step_add(&op.u.step_add, s);
         case FRIDO_OP_FILL: return frido_fill(&op.u.fill, s);
+        case FRIDO_OP_TIME_EMB: return frido_time_emb(&op.u.time_emb, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -160,6 +161,22 @@ extern "C" int frido_event_destroy(void* ev) {
     return FRIDO_OK;
 }
 
+int frido_igemm_init();
+extern "C" int frido_init(void) {
+    static std::once_flag once;
+    static int rc = FRIDO_OK;
+    std::call_once(once, [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+            frido_set_error("frido_init: no HIP device");
+            rc = FRIDO_EHIP;
+            return;
+        }
+        rc = frido_igemm_init();
+    });
+    return rc;
+}
+
 extern "C" int frido_abi_version(void) { return 1; }
 extern "C" int frido_sizeof_op(void) { return (int)sizeof(FridoOp); }
 extern "C" int frido_sizeof_desc(int32_t kind) {
@@ -178,6 +195,7 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_RANDN: return sizeof(FridoRandn);
         case FRIDO_OP_STEP_ADD: return sizeof(FridoStepAdd);
         case FRIDO_OP_FILL: return sizeof(FridoFill);
+        case FRIDO_OP_TIME_EMB: return sizeof(FridoTimeEmb);
         default: return -1;
     }
 }

@@ -223,5 +223,5 @@ def require_gpu(device):
     if device.type != "cuda":
         raise _lib.FridoHipError(
             f"the Frido hot path runs only on an MI355X HIP device (got device '{device}'); there is no CPU path")
-    _lib.lib()
+    _lib.check(_lib.lib().frido_init(), "frido_init")
     return device

@@ -1,0 +1,434 @@
+"""The reference's Python class / config / state_dict surface, running on the HIP engine.
+
+Each class keeps the constructor keywords, attribute names, method signatures and state_dict keys of
+its reference counterpart (cited per class) so that configs/frido/*.yaml `target:` strings and
+scripts/sample_diffusion.py keep working, but none of them contains a torch forward: tensors on a
+HIP device go through libfrido_hip.so, anything else raises FridoHipError (there is no CPU path).
+"""
+import contextlib
+import importlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import config, holders, schedules
+from ._lib import FridoHipError
+from .arch import unet_arch
+
+try:  # pytorch-lightning is optional (absent in this image): keep the LightningModule base when it exists
+    import pytorch_lightning as _pl
+    _Base = _pl.LightningModule
+except Exception:  # pragma: no cover
+    class _Base(nn.Module):
+        """Minimal stand-in for pl.LightningModule: `.device` + logging no-ops."""
+
+        @property
+        def device(self):
+            for t in list(self.parameters()) + list(self.buffers()):
+                return t.device
+            return torch.device("cpu")
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+
+# ---- config factory (frido/util.py:74-95) ---------------------------------------------------------
+def get_obj_from_str(string, reload=False):
+    module, cls = string.rsplit(".", 1)
+    mod = importlib.import_module(module, package=None)
+    if reload:
+        importlib.reload(mod)
+    return getattr(mod, cls)
+
+
+def _plain(cfg):
+    """OmegaConf / dict-like -> plain python containers."""
+    if hasattr(cfg, "items"):
+        return {k: _plain(v) for k, v in cfg.items()}
+    if isinstance(cfg, (list, tuple)) or type(cfg).__name__ == "ListConfig":
+        return [_plain(v) for v in cfg]
+    return cfg
+
+
+def instantiate_from_config(cfg):
+    if "target" not in cfg:
+        if cfg == "__is_first_stage__" or cfg == "__is_unconditional__":
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(cfg["target"])(**_plain(cfg.get("params", dict())))
+
+
+def instantiate_from_config_main(cfg, *args, **kwargs):
+    if "target" not in cfg:
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(cfg["target"])(*args, **_plain(cfg.get("params", dict())), **kwargs)
+
+
+def _no_cpu(what, device):
+    raise FridoHipError(f"{what}: tensors are on '{device}', but the Frido hot path runs only on an MI355X HIP device "
+                        "(move the model and its inputs with .cuda()); there is no CPU fallback")
+
+
+class _Versioned:
+    """Mixin: drops compiled HIP plans whenever the module's weights change."""
+
+    def _init_versioning(self):
+        self._rt = None
+        self._rt_key = None
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    def invalidate(self):
+        self._rt = None
+
+    def _apply(self, fn, *a, **k):   # .cuda() / .to() move the weights -> recompile
+        self._rt = None
+        return super()._apply(fn, *a, **k)
+
+
+# ---- denoiser (frido/modules/diffusionmodules/pyunet.py:447-950) -------------------------------------
+class PyUNetModel(_Versioned, nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 use_embed=False, num_stage=1, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True,
+                 use_split_head=False, split_embed_dim_list=[], use_SPADE_norm=False, use_pos_embed=False,
+                 use_mscond=False, use_stage_expert=False, precision=None):
+        super().__init__()
+        if use_spatial_transformer:
+            assert context_dim is not None, "context_dim is required with use_spatial_transformer"
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        unsupported = dict(num_classes=num_classes, use_pos_embed=use_pos_embed, use_mscond=use_mscond,
+                           use_stage_expert=use_stage_expert, n_embed=n_embed, resblock_updown=resblock_updown,
+                           use_scale_shift_norm=use_scale_shift_norm)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad or dims != 2 or not legacy or not conv_resample:
+            raise NotImplementedError(f"PyUNetModel options not used by any shipped Frido config: {bad}")
+        if use_split_head:
+            assert len(split_embed_dim_list) != 0 and sum(split_embed_dim_list) == in_channels
+        self.cfg = dict(image_size=image_size, in_channels=in_channels, model_channels=model_channels,
+                        out_channels=out_channels, num_res_blocks=num_res_blocks,
+                        attention_resolutions=list(attention_resolutions), channel_mult=list(channel_mult),
+                        num_head_channels=num_head_channels, num_heads=num_heads,
+                        use_spatial_transformer=use_spatial_transformer, transformer_depth=transformer_depth,
+                        context_dim=context_dim, num_stage=num_stage, use_split_head=use_split_head,
+                        split_embed_dim_list=list(split_embed_dim_list), use_SPADE_norm=use_SPADE_norm)
+        self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions, self.dropout = num_res_blocks, attention_resolutions, dropout
+        self.channel_mult, self.conv_resample, self.num_classes = channel_mult, conv_resample, num_classes
+        self.dtype = torch.float32
+        self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+        self.predict_codebook_ids = False
+        self.num_stage, self.use_split_head = num_stage, use_split_head
+        self.split_embed_dim_list, self.use_SPADE_norm = list(split_embed_dim_list), use_SPADE_norm
+        self.precision = precision
+        self.arch = holders.build_unet_params(self, self.cfg)
+        self._init_versioning()
+
+    def runtime(self, precision=None):
+        from .runtime import DenoiserRuntime
+        dev = next(self.parameters()).device
+        key = (str(dev), precision or self.precision or config.PRECISION)
+        if self._rt is None or self._rt_key != key:
+            if dev.type != "cuda":
+                _no_cpu("PyUNetModel", dev)
+            self._rt = DenoiserRuntime(self, self.cfg, dev, key[1])
+            self._rt_key = key
+        return self._rt
+
+    def forward(self, x, timesteps=None, context=None, y=None, stage=None, **kwargs):
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        if not x.is_cuda:
+            _no_cpu("PyUNetModel.forward", x.device)
+        if self.num_stage > 1 and not isinstance(stage, int):
+            stage = int(stage)
+        return self.runtime().forward(x, timesteps, context, stage)
+
+
+UNetModel = PyUNetModel   # `ldm.modules.diffusionmodules.openaimodel.UNetModel` alias used by two shipped configs
+
+
+# ---- first stage (taming/models/msvqgan.py:16-96,320-399) ---------------------------------------------
+class DummyLoss(nn.Module):   # taming/modules/losses/vqperceptual.py:12-14
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+class _Quantizer(nn.Module):
+    """VectorQuantizer2 holder (taming/modules/vqvae/quantize.py:214-241): codebook in `.embedding.weight`."""
+
+    def __init__(self, n_e, e_dim, beta=0.25):
+        super().__init__()
+        self.n_e, self.e_dim, self.beta = n_e, e_dim, beta
+        self.embedding = holders.Emb(n_e, e_dim)
+
+
+class VQModelInterface(_Versioned, _Base):
+    def __init__(self, embed_dim, channel_range=[], edconfig=None, ddconfig=None, lossconfig=None, n_embed=None,
+                 fusion="concat", ckpt_path=None, ignore_keys=[], image_key="image", colorize_nlabels=None, monitor=None,
+                 remap=None, sane_index_shape=False, on_vit=[], use_aux_loss=False, unsample_type="nearest",
+                 quant_beta=0.25, legacy=True, init_normal=False, precision=None):
+        super().__init__()
+        edconfig, ddconfig = _plain(edconfig), _plain(ddconfig)
+        embed_dim, n_embed = list(embed_dim), list(n_embed)
+        assert fusion == "concat" and remap is None, "only the 'concat' fusion without remap is used by Frido configs"
+        assert len(n_embed) == edconfig["multiscale"] == len(embed_dim), "multiscale mode. dim of n_embed is incorrect."
+        self.image_key, self.fusion = image_key, fusion
+        self.embed_dim, self.n_embed, self.channel_range = embed_dim, n_embed, channel_range
+        self.edconfig, self.ddconfig = edconfig, ddconfig
+        self.vq_cfg = dict(embed_dim=embed_dim, n_embed=n_embed, edconfig=edconfig, ddconfig=ddconfig)
+        self.precision = precision
+        holders.build_msvqgan_params(self, edconfig, ddconfig, n_embed, embed_dim)
+        for i, q in enumerate(self.ms_quantize):
+            q.n_e, q.e_dim, q.beta = n_embed[i], embed_dim[i], quant_beta
+        self.encoder.num_resolutions = len(edconfig["ch_mult"])
+        self.encoder.multiscale = edconfig["multiscale"]
+        self.encoder.resolution = edconfig["resolution"]
+        self.loss = DummyLoss()
+        nres = len(edconfig["ch_mult"])
+        self.res_list = [edconfig["resolution"] / 2 ** (nres - i - 1) for i in range(edconfig["multiscale"])]
+        if monitor is not None:
+            self.monitor = monitor
+        self._init_versioning()
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        self.load_state_dict(sd, strict=False)
+
+    def runtime(self):
+        from .runtime import DecoderRuntime
+        dev = next(self.parameters()).device
+        key = (str(dev), self.precision or config.PRECISION)
+        if self._rt is None or self._rt_key != key:
+            if dev.type != "cuda":
+                _no_cpu("VQModelInterface", dev)
+            self._rt = DecoderRuntime(self, self.vq_cfg, dev, key[1])
+            self._rt_key = key
+        return self._rt
+
+    @torch.no_grad()
+    def decode(self, h_in, force_not_quantize=False, return_code=False, inv_scale=None):
+        """msvqgan.py:376-399.  Returns dec (B,3,H,W) [and per-scale code lists when return_code]."""
+        if not h_in.is_cuda:
+            _no_cpu("VQModelInterface.decode", h_in.device)
+        out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code)
+        if return_code:
+            dec, idx = out
+            return dec, [i.tolist() for i in idx]     # the reference's host lists (msvqgan.py:390)
+        return out
+
+    def encode(self, x):
+        raise FridoHipError("VQModelInterface.encode (SURVEY.md §8 a16) is not on the HIP path yet — next row of the "
+                            "scope table; sampling from random latents does not need it")
+
+
+# ---- EMA shadow (frido/modules/ema.py) ---------------------------------------------------------------
+class LitEma(nn.Module):
+    def __init__(self, model, decay=0.9999, use_num_upates=True):
+        super().__init__()
+        self.m_name2s_name = {}
+        self.register_buffer("decay", torch.tensor(decay, dtype=torch.float32))
+        self.register_buffer("num_updates", torch.tensor(0 if use_num_upates else -1, dtype=torch.int))
+        for name, p in model.named_parameters():
+            s_name = name.replace(".", "")
+            self.m_name2s_name[name] = s_name
+            self.register_buffer(s_name, p.clone().detach().data)
+        self.collected_params = []
+
+    def copy_to(self, model):
+        shadow = dict(self.named_buffers())
+        for key, p in model.named_parameters():
+            p.data.copy_(shadow[self.m_name2s_name[key]].data)
+
+    def store(self, parameters):
+        self.collected_params = [p.clone() for p in parameters]
+
+    def restore(self, parameters):
+        for c, p in zip(self.collected_params, parameters):
+            p.data.copy_(c.data)
+
+
+# ---- diffusion wrapper + main module (frido/models/diffusion/frido.py) ----------------------------------
+class DiffusionWrapper(_Base):
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+        assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
+
+    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, stage=None):
+        if self.conditioning_key == "crossattn":
+            return self.diffusion_model(x, t, context=torch.cat(c_crossattn, 1), stage=stage)
+        raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: every shipped Frido config uses 'crossattn'")
+
+
+class FridoDiffusion(_Base):
+    """frido.py:45-124 (DDPM.__init__) + 478-555 (FridoDiffusion.__init__), inference subset."""
+
+    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="image",
+                 cond_stage_trainable=False, concat_mode=True, cond_stage_forward=None, conditioning_key=None,
+                 scale_factor=1.0, use_prob=False, scale_by_std=False, disable_log_image=False, plot_sample=True,
+                 plot_inpaint=True, plot_denoise_rows=True, plot_progressive_rows=True, plot_diffusion_rows=True,
+                 plot_quantize_denoised=True, adopted_scale_factor=False, adopted_scale_factor_value=None,
+                 noise_mix_ratio=0, stage_loss_ratio=[0.5, 0.5],
+                 unet_config=None, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None, ignore_keys=[],
+                 load_only_unet=False, monitor="val/loss", use_ema=True, first_stage_key="image", image_size=256,
+                 channels=3, log_every_t=100, clip_denoised=True, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3,
+                 given_betas=None, original_elbo_weight=0., v_posterior=0., l_simple_weight=1., parameterization="eps",
+                 scheduler_config=None, use_positional_encodings=False, learn_logvar=False, logvar_init=0.,
+                 specify_channels=[], **ignored):
+        super().__init__()
+        assert parameterization == "eps", "Frido samples in eps-prediction mode"
+        unet_config = _plain(unet_config)
+        self.parameterization = parameterization
+        self.num_timesteps_cond = 1 if num_timesteps_cond is None else num_timesteps_cond
+        self.scale_by_std, self.adopted_scale_factor = scale_by_std, adopted_scale_factor
+        self.cond_stage_model = None
+        self.clip_denoised = False
+        self.log_every_t, self.first_stage_key, self.image_size, self.channels = log_every_t, first_stage_key, image_size, channels
+        if conditioning_key is None:
+            conditioning_key = "concat" if concat_mode else "crossattn"
+        if cond_stage_config == "__is_unconditional__":
+            conditioning_key = None
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.specify_channels = specify_channels
+        self.unet_config = unet_config
+        self.use_split_head = unet_config["params"].get("use_split_head", False)
+        self.split_embed_dim_list = unet_config["params"].get("split_embed_dim_list", [])
+        self.use_ema = use_ema
+        if use_ema:
+            self.model_ema = LitEma(self.model)
+        self.v_posterior = v_posterior
+        if monitor is not None:
+            self.monitor = monitor
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
+                               linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        self.concat_mode, self.cond_stage_trainable, self.cond_stage_key = concat_mode, cond_stage_trainable, cond_stage_key
+        self.cond_stage_forward = cond_stage_forward
+        self.use_prob = use_prob
+        self.instantiate_first_stage(first_stage_config)
+        self.instantiate_cond_stage(cond_stage_config)
+        n_scale = len(self.first_stage_model.embed_dim)
+        if not scale_by_std:
+            self.scale_factor = scale_factor
+        elif not adopted_scale_factor:
+            self.register_buffer("scale_factor", torch.tensor(scale_factor))
+        else:
+            self.register_buffer("scale_factor", torch.tensor([scale_factor for _ in range(n_scale)]))
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+
+    # -- schedule buffers (frido.py:127-155) --
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else schedules.make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        self.num_timesteps = int(np.asarray(betas).shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        for k, v in schedules.ddpm_tables(betas).items():
+            self.register_buffer(k, torch.from_numpy(v))
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        target = self.model if only_model else self
+        return target.load_state_dict(sd, strict=False)
+
+    def instantiate_first_stage(self, cfg):
+        model = instantiate_from_config(_plain(cfg))
+        self.first_stage_model = model.eval()
+        for p in self.first_stage_model.parameters():
+            p.requires_grad = False
+        self.num_resulotion = len(self.first_stage_model.res_list)
+        self.embed_dim_list = self.first_stage_model.embed_dim
+
+    def instantiate_cond_stage(self, cfg):
+        if cfg in ("__is_first_stage__",):
+            self.cond_stage_model = self.first_stage_model
+        elif cfg == "__is_unconditional__":
+            self.cond_stage_model = None
+        else:
+            self.cond_stage_model = instantiate_from_config(_plain(cfg))
+            if self.cond_stage_model is not None:
+                self.cond_stage_model.eval()
+
+    @contextlib.contextmanager
+    def ema_scope(self, context=None):
+        """frido.py:181-194: sample with the EMA weights, then restore."""
+        if self.use_ema:
+            self.model_ema.store(self.model.parameters())
+            self.model_ema.copy_to(self.model)
+            self.model.diffusion_model.invalidate()
+            if context is not None:
+                print(f"{context}: Switched to EMA weights")
+        try:
+            yield None
+        finally:
+            if self.use_ema:
+                self.model_ema.restore(self.model.parameters())
+                self.model.diffusion_model.invalidate()
+                if context is not None:
+                    print(f"{context}: Restored training weights")
+
+    def get_learned_conditioning(self, c):
+        """frido.py:664-675."""
+        if self.cond_stage_forward is None:
+            if hasattr(self.cond_stage_model, "encode") and callable(self.cond_stage_model.encode):
+                return self.cond_stage_model.encode(c)
+            return self.cond_stage_model(c)
+        return getattr(self.cond_stage_model, self.cond_stage_forward)(c)
+
+    def get_first_stage_encoding(self, z):
+        """frido.py:647-662 (tensor branch)."""
+        if not self.adopted_scale_factor:
+            return self.scale_factor * z
+        start = 0
+        for i, e in enumerate(self.first_stage_model.embed_dim):
+            if start + e <= z.size(1):
+                z[:, start:start + e] *= self.scale_factor[i]
+                start += e
+        return z.clone()
+
+    def apply_model(self, x_noisy, t, cond, stage=None, return_ids=False):
+        """frido.py:1062-1160 (no split_input_params)."""
+        if not isinstance(cond, dict):
+            if not isinstance(cond, list):
+                cond = [cond]
+            cond = {"c_concat" if self.model.conditioning_key == "concat" else "c_crossattn": cond}
+        out = self.model(x_noisy, t, stage=stage, **cond)
+        return out[0] if isinstance(out, tuple) and not return_ids else out
+
+    @torch.no_grad()
+    def decode_first_stage(self, z_in, predict_cids=False, force_not_quantize=False, return_code=False):
+        """frido.py:823-891: per-scale 1/scale_factor (fused into the VQ kernel) + first-stage decode."""
+        assert not predict_cids
+        embed = self.first_stage_model.embed_dim
+        if not self.adopted_scale_factor:
+            sf = float(self.scale_factor)
+            inv = [float(np.float32(1.0) / np.float32(sf))] * len(embed)
+        else:
+            sfs = self.scale_factor.detach().float().cpu().numpy()
+            inv = [float(np.float32(1.0) / np.float32(v)) for v in sfs]
+        return self.first_stage_model.decode(z_in, return_code=return_code, inv_scale=inv)
+
+    def encode_first_stage(self, x):
+        return self.first_stage_model.encode(x)
+
+    def forward(self, *a, **k):
+        raise FridoHipError("training (FridoDiffusion.forward / p_losses) is outside the inference hot path")
+
+
+MSLatentDiffusion = FridoDiffusion   # stale alias `ldm.models.diffusion.msldm.MSLatentDiffusion` in two shipped configs

@@ -1,0 +1,324 @@
+"""Runtimes that own compiled HIP programs for a model instance.
+
+  DenoiserRuntime  — PyUNetModel.forward(x, t, context, stage) on the HIP engine (API path);
+  SamplerEngine    — the multi-stage DDIM / PLMS loop with per-sample invariants hoisted, the per-step
+                     body captured in a hipGraph, a device step counter and coefficient tables
+                     (reference: frido/models/diffusion/ddim.py:116-273, plms.py:116-303);
+  DecoderRuntime   — VQModelInterface.decode / decode_first_stage on the HIP engine.
+"""
+import numpy as np
+import torch
+
+from . import _lib, config
+from .builder import Builder
+from .engine import current_stream_ptr, require_gpu
+from .schedules import sampler_coef_table, COEF_ROW
+from .unet_plan import UNetStagePlan
+from .vqgan_plan import VQDecodePlan
+
+
+def _weights_of(module, device):
+    return {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in module.state_dict().items()}
+
+
+def _run1(builder, kind, stream, **kw):
+    """Launch a single op immediately."""
+    from .engine import Prog
+    p = Prog(builder.device, builder.nsplit)
+    p.emit(kind, **kw)
+    p.run(stream)
+
+
+class DenoiserRuntime:
+    def __init__(self, module, cfg, device, precision=None):
+        self.device = require_gpu(device)
+        self.cfg = cfg
+        self.nsplit = config.nsplit(precision)
+        self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
+        self.plans = {}
+
+    def forward(self, x, t, context, stage):
+        """x (B, Cin, H, W) f32 cuda NCHW, t (B,) int64, context (B, nctx, cd) -> eps (B, nch, H, W)."""
+        B, Cin, H, W = x.shape
+        nctx = context.shape[1]
+        stage = 0 if stage is None else int(stage)
+        key = (B, H, W, nctx, stage, Cin)
+        st = current_stream_ptr(self.device)
+        if key not in self.plans:
+            x_state = torch.zeros(B, H * W, Cin, dtype=torch.float32, device=self.device)
+            self.plans[key] = UNetStagePlan(self.b, self.cfg, B=B, H=H, W=W, nctx=nctx, stage=stage, x_state=x_state,
+                                            temb_rows=B, per_sample_t=True)
+        plan = self.plans[key]
+        xc = x.contiguous().float()
+        _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=xc.data_ptr(), dst=plan.x_state.data_ptr(), B=B, HW=H * W, Csrc=Cin,
+              c0=0, Cuse=Cin, Cdst=Cin, d0=0, to_nchw=0)
+        plan.set_context(context.to(torch.float32))
+        plan.set_timesteps(t.to(torch.int64))
+        plan.pre.run(st)
+        plan.step.run(st)
+        out = torch.empty(B, plan.nch, H, W, dtype=torch.float32, device=self.device)
+        _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=plan.eps.data_ptr(), dst=out.data_ptr(), B=B, HW=H * W, Csrc=plan.nch,
+              c0=0, Cuse=plan.nch, Cdst=plan.nch, d0=0, to_nchw=1)
+        return out
+
+
+class SamplerEngine:
+    """One instance per (denoiser weights, B, latent shape, context length, S, eta, cfg on/off, kind)."""
+
+    def __init__(self, builder: Builder, cfg, *, B, C, H, W, nctx, S, eta, kind, alphas_cumprod, embed_dim, cfg_scale=1.0,
+                 use_graph=True, num_stage=None, temperature=1.0):
+        self.b, self.cfg = builder, cfg
+        self.dev = builder.device
+        self.B, self.C, self.H, self.W, self.nctx = B, C, H, W, nctx
+        self.kind = kind
+        self.cfg_scale = float(cfg_scale)
+        self.xrep = 2 if self.cfg_scale != 1.0 else 1
+        self.embed = list(embed_dim)
+        self.num_stage = num_stage if num_stage is not None else cfg.get("num_stage", 1)
+        self.use_graph = use_graph
+        self.temperature = float(temperature)
+        tab, self.t_loop = sampler_coef_table(np.asarray(alphas_cumprod, dtype=np.float32), S, eta, plms=(kind == "plms"))
+        self.n_steps = tab.shape[0]
+        self.coef = torch.from_numpy(tab).to(self.dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.rng = torch.zeros(2, dtype=torch.int64, device=self.dev)   # {seed, sample0} read by the captured kernels
+        self.x = torch.zeros(B, H * W, C, dtype=torch.float32, device=self.dev)
+        self.pred_x0 = torch.zeros_like(self.x)
+        self.stages = []
+        for s in range(self.num_stage):
+            plan = UNetStagePlan(self.b, cfg, B=B, H=H, W=W, nctx=nctx, stage=s, x_state=self.x, temb_rows=self.n_steps,
+                                 per_sample_t=False, step_ptr=self.step.data_ptr(), xrep=self.xrep)
+            self.stages.append(plan)
+        self.graphs = {}
+        self.noise_buf = None
+        self._stream = None
+        # PLMS state
+        if kind == "plms":
+            nmax = max(self.embed[:self.num_stage])
+            self.hist = [torch.zeros(B * H * W, nmax, dtype=torch.float32, device=self.dev) for _ in range(4)]
+            self.x_save = torch.zeros_like(self.x)
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _stream_ptr(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.dev)
+        return self._stream
+
+    def _sampler_op(self, s, *, noise_ptr, noise_C, seed, sample0, write_x=1, x_out=None, eps_out=None, hist=(),
+                    row_offset=0):
+        plan = self.stages[s]
+        start = sum(self.embed[:s])
+        nch = self.embed[s]
+        BHW = self.B * self.H * self.W
+        kw = dict(x=self.x.data_ptr(), B=self.B, HW=self.H * self.W, Cx=self.C, start=start, nch=nch,
+                  eps_cond=plan.eps.data_ptr(), cfg_scale=self.cfg_scale, coef=self.coef.data_ptr(),
+                  step=self.step.data_ptr(), coef_row_offset=row_offset, temperature=self.temperature,
+                  x_out=(x_out if x_out is not None else self.x.data_ptr()), pred_x0=self.pred_x0.data_ptr(),
+                  write_x=write_x, seed=seed, sample0=sample0, rng_stream=s + 1, rng_dev=self.rng.data_ptr())
+        if self.xrep == 2:
+            kw["eps_uncond"] = plan.eps.data_ptr() + 4 * BHW * nch
+        if noise_ptr:
+            kw.update(noise=noise_ptr, noise_stride=BHW * noise_C, noise_C=noise_C, noise_c0=start)
+        if eps_out is not None:
+            kw["eps_out"] = eps_out
+        for i, h in enumerate(hist):
+            kw[f"hist{i + 1}"] = h
+        return kw
+
+    def _upload_noise(self, s, tape):
+        """tape: list of per-step NCHW tensors (B, 3(s+1), H, W) in draw order -> NHWC device buffer."""
+        Cs = sum(self.embed[:s + 1])
+        t = torch.stack([torch.as_tensor(n, dtype=torch.float32) for n in tape])     # [n][B][Cs][H][W]
+        assert t.shape[1:] == (self.B, Cs, self.H, self.W), (t.shape, Cs)
+        self.noise_buf = t.permute(0, 1, 3, 4, 2).contiguous().to(self.dev)          # plumbing: layout + H2D
+        return self.noise_buf.data_ptr(), Cs
+
+    # ---- main entry --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def run(self, cond, uncond=None, *, x_T=None, noise="philox", seed=0, sample0=0, log_every_t=100, callback=None,
+            img_callback=None):
+        """Runs all stages.  noise: "philox" (device counter RNG), "torch" (draw from torch's global CPU generator in
+        exactly the reference's order — same seeds give the reference's noise stream), or a callable
+        shape -> tensor replaying a recorded tape.  Returns (samples NCHW, intermediates dict)."""
+        B, C, H, W = self.B, self.C, self.H, self.W
+        stream = self._stream_ptr()
+        stream.wait_stream(torch.cuda.current_stream(self.dev))
+        sp = stream.cuda_stream
+        draw = None
+        if noise == "torch":
+            draw = lambda shape: torch.randn(shape)
+        elif callable(noise):
+            draw = noise
+        with torch.cuda.stream(stream):
+            ctx = cond.to(self.dev, torch.float32)
+            if self.xrep == 2:
+                ctx = torch.cat([ctx, uncond.to(self.dev, torch.float32)], dim=0)
+            # ---- x_T (ddim.py:127-130) ----
+            if x_T is not None:
+                xt = torch.as_tensor(x_T, dtype=torch.float32)
+            elif draw is not None:
+                xt = draw((B, C, H, W))
+            else:
+                xt = None
+            if xt is not None:
+                xd = xt.to(self.dev).contiguous()
+                _run1(self.b, "FRIDO_OP_RELAYOUT", sp, src=xd.data_ptr(), dst=self.x.data_ptr(), B=B, HW=H * W, Csrc=C,
+                      c0=0, Cuse=C, Cdst=C, d0=0, to_nchw=0)
+            else:
+                _run1(self.b, "FRIDO_OP_RANDN", sp, dst=self.x.data_ptr(), n=B * H * W * C, per_sample=H * W * C, seed=seed,
+                      sample0=sample0, rng_stream=0)
+            x0_nchw = self._to_nchw(self.x, sp)
+            inter = {"x_inter": [x0_nchw], "pred_x0": [x0_nchw]}
+            t_loop = torch.from_numpy(self.t_loop.astype(np.int64)).to(self.dev)
+            n = self.n_steps
+            for s in range(self.num_stage):
+                plan = self.stages[s]
+                Cs = sum(self.embed[:s + 1])
+                plan.set_context(ctx)
+                plan.set_timesteps(t_loop)
+                self.step.zero_()
+                plan.pre.run(sp)
+                if self.kind == "ddim":
+                    self._ddim_stage(s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs)
+                else:
+                    self._plms_stage(s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs)
+                if self.num_stage != 1:
+                    levels = self.num_stage - s - 1
+                    if levels > 0:
+                        c0, c1 = sum(self.embed[:s]), sum(self.embed[:s + 1])
+                        _run1(self.b, "FRIDO_OP_HANDOFF", sp, x=self.x.data_ptr(), B=B, H=H, W=W, Cx=C, c0=c0, c1=c1,
+                              levels=levels)
+                        # the reference mutates the logged tensor in place (ddim.py:185): mirror that
+                        if inter["x_inter"] and getattr(self, "_last_logged_stage", None) == s:
+                            inter["x_inter"][-1] = self._to_nchw(self.x, sp)[:, :Cs]
+            out = self._to_nchw(self.x, sp)
+        torch.cuda.current_stream(self.dev).wait_stream(stream)
+        return out, inter
+
+    def _to_nchw(self, nhwc, sp):
+        B, H, W = self.B, self.H, self.W
+        C = nhwc.shape[-1]
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=self.dev)
+        _run1(self.b, "FRIDO_OP_RELAYOUT", sp, src=nhwc.data_ptr(), dst=out.data_ptr(), B=B, HW=H * W, Csrc=C, c0=0,
+              Cuse=C, Cdst=C, d0=0, to_nchw=1)
+        return out
+
+    def _log(self, s, i, inter, log_every_t, sp, Cs, callback, img_callback):
+        n = self.n_steps
+        index = n - i - 1
+        if callback:
+            callback(i)
+        if img_callback:
+            img_callback(self._to_nchw(self.pred_x0, sp)[:, :Cs], i)
+        if index % log_every_t == 0 or index == n - 1:
+            inter["x_inter"].append(self._to_nchw(self.x, sp)[:, :Cs])
+            inter["pred_x0"].append(self._to_nchw(self.pred_x0, sp)[:, :Cs])
+            self._last_logged_stage = s if i == n - 1 else None
+
+    def _ddim_stage(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs):
+        """ddim.py:155-175.  Philox mode replays ONE captured hipGraph per step (denoiser forward + state update +
+        step-counter bump); tape mode (recorded / torch-CPU noise) runs the same ops eagerly."""
+        from .engine import Prog
+        plan = self.stages[s]
+        n = self.n_steps
+        if draw is not None:
+            noise_ptr, noise_C = self._upload_noise(s, [draw((self.B, Cs, self.H, self.W)) for _ in range(n)])
+            body = Prog(self.dev, self.b.nsplit)
+            body.ops = list(plan.step.ops)
+            body.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=noise_ptr, noise_C=noise_C, seed=0, sample0=0))
+            body.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
+            launch = lambda: body.run(sp)
+        else:
+            self.rng.copy_(torch.tensor([seed, sample0], dtype=torch.int64))
+            key = ("ddim", s)
+            if key not in self.graphs:
+                full = Prog(self.dev, self.b.nsplit)
+                full.ops = list(plan.step.ops)
+                full.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0))
+                full.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
+                full.keep = [plan]
+                self.graphs[key] = full.capture(sp) if self.use_graph else full
+            g = self.graphs[key]
+            launch = (lambda: g.launch(sp)) if self.use_graph else (lambda: g.run(sp))
+        for i in range(n):
+            launch()
+            self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
+
+    def _plms_stage(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs):
+        """plms.py:156-194,285-303: Heun-style first step (two denoiser calls), then Adams-Bashforth 2/3/4."""
+        from .engine import Prog
+        plan = self.stages[s]
+        n = self.n_steps
+        key = ("plms_fwd", s)
+        fwd = self.graphs.get(key)
+        if fwd is None:
+            fwd = plan.step.capture(sp) if self.use_graph else plan.step
+            self.graphs[key] = fwd
+        go = (lambda: fwd.launch(sp)) if self.use_graph else (lambda: fwd.run(sp))
+        nch = self.embed[s]
+        hist = [h.data_ptr() for h in self.hist]
+
+        def tail(**kw):
+            p = Prog(self.dev, self.b.nsplit)
+            p.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=seed, sample0=sample0, **kw))
+            return p
+
+        for i in range(n):
+            # eta == 0: the reference still draws (and discards) noise for every update; keep the CPU stream in step
+            if draw is not None:
+                draw((self.B, Cs, self.H, self.W))
+            go()
+            if i == 0:
+                # x_prev with e_t (scratch), e_next = eps(x_prev, t_next), e' = (e_t + e_next) / 2
+                if draw is not None:
+                    draw((self.B, Cs, self.H, self.W))
+                self.x_save.copy_(self.x)
+                p = tail(eps_out=hist[0])
+                p.run(sp)                                   # x <- x_prev(e_t); hist[0] <- e_t
+                if n > 1:
+                    _run1(self.b, "FRIDO_OP_STEP_ADD", sp, step=self.step.data_ptr(), delta=1)
+                go()                                        # eps(x_prev, t_next)
+                if n > 1:
+                    _run1(self.b, "FRIDO_OP_STEP_ADD", sp, step=self.step.data_ptr(), delta=-1)
+                self.x.copy_(self.x_save)
+                p = tail(hist=(hist[0],))                   # row 0 carries ab = (1, 1) / 2
+                p.run(sp)
+            else:
+                k = min(i, 3)
+                older = tuple(hist[(i - j) % 4] for j in range(1, k + 1))
+                p = tail(eps_out=hist[i % 4], hist=older)
+                p.run(sp)
+            _run1(self.b, "FRIDO_OP_STEP_ADD", sp, step=self.step.data_ptr(), delta=1)
+            self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
+
+
+class DecoderRuntime:
+    def __init__(self, module, vq_cfg, device, precision=None):
+        self.device = require_gpu(device)
+        self.cfg = vq_cfg
+        self.nsplit = config.nsplit(precision)
+        self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
+        self.plans = {}
+
+    def decode(self, z, inv_scale=None, return_code=False):
+        """z (B, Ctot, h, w) NCHW latent -> image (B, 3, H, W); inv_scale: per-scale multiplier (1/scale_factor)."""
+        B, Ct, h, w = z.shape
+        embed = self.cfg["embed_dim"]
+        inv = tuple(float(v) for v in (inv_scale if inv_scale is not None else [1.0] * len(embed)))
+        key = (B, h, w, inv)
+        st = current_stream_ptr(self.device)
+        if key not in self.plans:
+            z_state = torch.zeros(B, h * w, Ct, dtype=torch.float32, device=self.device)
+            self.plans[key] = (z_state, VQDecodePlan(self.b, self.cfg["ddconfig"], embed, self.cfg["n_embed"], B=B, h=h, w=w,
+                                                      z_state=z_state, inv_scale=inv))
+        z_state, plan = self.plans[key]
+        zc = z.contiguous().float()
+        _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=zc.data_ptr(), dst=z_state.data_ptr(), B=B, HW=h * w, Csrc=Ct, c0=0,
+              Cuse=Ct, Cdst=Ct, d0=0, to_nchw=0)
+        plan.prog.run(st)
+        out = torch.empty(B, plan.a.out_ch, plan.H, plan.W, dtype=torch.float32, device=self.device)
+        _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=plan.out_nhwc.data_ptr(), dst=out.data_ptr(), B=B, HW=plan.H * plan.W,
+              Csrc=plan.a.out_ch, c0=0, Cuse=plan.a.out_ch, Cdst=plan.a.out_ch, d0=0, to_nchw=1)
+        if return_code:
+            return out, [i.view(B, -1) for i in plan.idx]
+        return out

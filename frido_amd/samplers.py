@@ -1,0 +1,86 @@
+"""DDIMSampler / PLMSSampler with the reference's constructor and `.sample(...)` signature
+(frido/models/diffusion/ddim.py:11-114, plms.py:11-114), driving the HIP SamplerEngine.
+
+Noise: the reference draws x_T and one torch.randn per update from torch's global generator.  With
+noise="torch" (default) the same draws are made on the host in the same order and uploaded, so a run
+after torch.manual_seed(s) consumes exactly the reference's noise stream; noise="philox" uses the
+device counter RNG keyed by (seed, global sample index) instead (no host involvement, shard-invariant).
+"""
+import numpy as np
+import torch
+
+from . import schedules
+from ._lib import FridoHipError
+
+
+class _SamplerBase:
+    KIND = "ddim"
+
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        if self.KIND == "plms" and ddim_eta != 0:
+            raise ValueError("ddim_eta must be 0 for PLMS")
+        ac = self.model.alphas_cumprod.detach().float().cpu().numpy()
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        self.ddim_timesteps = schedules.make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        sig, al, alp = schedules.make_ddim_sampling_parameters(ac, self.ddim_timesteps, ddim_eta)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, al, alp
+        self.ddim_sqrt_one_minus_alphas = np.sqrt((np.float32(1.0) - al).astype(np.float32))
+        self.alphas_cumprod = ac
+
+    def _engine(self, B, shape, nctx, S, eta, scale, num_stage, temperature):
+        from .runtime import SamplerEngine
+        unet = self.model.model.diffusion_model
+        rt = unet.runtime()
+        C, H, W = shape
+        key = (self.KIND, B, C, H, W, nctx, S, float(eta), scale != 1.0, num_stage, float(temperature))
+        cache = rt.__dict__.setdefault("_sampler_engines", {})
+        if key not in cache:
+            cache[key] = SamplerEngine(rt.b, unet.cfg, B=B, C=C, H=H, W=W, nctx=nctx, S=S, eta=eta, kind=self.KIND,
+                                       alphas_cumprod=self.model.alphas_cumprod.detach().float().cpu().numpy(),
+                                       embed_dim=self.model.embed_dim_list, cfg_scale=scale, num_stage=num_stage,
+                                       temperature=temperature)
+        eng = cache[key]
+        eng.cfg_scale = float(scale)
+        return eng
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, num_stage=1, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
+               score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, noise="torch", seed=0, sample0=0,
+               **kwargs):
+        if mask is not None or x0 is not None or score_corrector is not None or quantize_x0 or noise_dropout > 0.:
+            raise NotImplementedError("mask / x0 / score_corrector / quantize_x0 / noise_dropout are not on the HIP path "
+                                      "(no shipped Frido sampling script uses them; quantize_x0 exit()s in the reference)")
+        if conditioning is None or isinstance(conditioning, dict):
+            raise NotImplementedError("cross-attention conditioning tensor required")
+        if conditioning.shape[0] != batch_size and verbose:
+            print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        if not conditioning.is_cuda:
+            raise FridoHipError("sample(): conditioning must live on the MI355X (there is no CPU path)")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        if unconditional_guidance_scale != 1.:
+            assert unconditional_conditioning is not None
+        eng = self._engine(batch_size, tuple(shape), conditioning.shape[1], S, eta, unconditional_guidance_scale, num_stage,
+                           temperature)
+        if verbose:
+            print(f"Data shape for {self.KIND.upper()} sampling is {(batch_size, *shape)}, eta {eta}")
+        self.num_stage = num_stage
+        return eng.run(conditioning, unconditional_conditioning, x_T=x_T, noise=noise, seed=seed, sample0=sample0,
+                       log_every_t=log_every_t, callback=callback, img_callback=img_callback)
+
+
+class DDIMSampler(_SamplerBase):
+    KIND = "ddim"
+
+
+class PLMSSampler(_SamplerBase):
+    KIND = "plms"

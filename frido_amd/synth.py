@@ -52,3 +52,14 @@ def fill_state_dict(shapes, skip=()):
 def seeded_normal(tag, shape):
     """Standard-normal float32 input tensor keyed by a string tag (test/bench inputs)."""
     return _rng("input:" + tag).standard_normal(tuple(shape)).astype(np.float32)
+
+
+def fill_module(module, prefix=""):
+    """Fill every parameter of an nn.Module in place from the deterministic filler (keyed by prefix+name)."""
+    import torch
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            p.copy_(torch.from_numpy(fill_tensor(prefix + name, p.shape)).to(p.device))
+    if hasattr(module, "invalidate"):
+        module.invalidate()
+    return module

@@ -1,0 +1,332 @@
+"""Compiles the Frido denoiser (reference: frido/modules/diffusionmodules/pyunet.py:867-950) into
+HIP programs for one (batch, latent size, context length, stage).
+
+Two programs per stage:
+  * pre  — everything that does not change from step to step and is hoisted out of the sampling loop
+           (SURVEY.md §0 facts 8, §2b K9/K10): the timestep/stage embedding table for all S steps and
+           the per-ResBlock `emb_layers` projections of it, cross-attention K / V^T of the context,
+           and (stage >= 1) the SPADE conditioning feature map with every gamma/beta map;
+  * step — one denoiser forward reading the NHWC f32 latent state and writing eps.
+Layout: activations NHWC, f32 residual stream + bf16 (hi/lo) operand tensors feeding the MFMA GEMM.
+"""
+import numpy as np
+import torch
+
+from .arch import unet_arch
+from .builder import Builder, ACT_NONE, ACT_RELU, ACT_SILU
+from .engine import rup
+
+
+class UNetStagePlan:
+    def __init__(self, b: Builder, cfg, *, B, H, W, nctx, stage, x_state, temb_rows, per_sample_t, step_ptr=None,
+                 xrep=1, hoist=True):
+        """x_state: f32 device tensor [B][H*W][Ctot] (NHWC latent).  The denoiser runs on a logical batch
+        Bx = B * xrep (xrep = 2 for classifier-free guidance: [cond | uncond] share x, differ in context).
+        temb_rows: number of rows of the timestep table (S in sampler mode, Bx when per_sample_t)."""
+        self.b, self.cfg = b, cfg
+        a = self.a = unet_arch(cfg)
+        self.B, self.H, self.W, self.nctx, self.stage, self.xrep = B, H, W, nctx, stage, xrep
+        self.Bx = B * xrep
+        self.x_state = x_state
+        self.Ctot = x_state.shape[-1]
+        self.per_sample_t = per_sample_t
+        self.step_ptr = step_ptr
+        self.temb_rows = temb_rows
+        dev = b.device
+        self.t_dev = torch.zeros(temb_rows, dtype=torch.int64, device=dev)
+        self.ctx_in = torch.zeros(self.Bx, nctx, a.context_dim, dtype=torch.float32, device=dev)
+        self.nch = a.splits[stage] if a.use_split_head else cfg["out_channels"]
+        self.eps = torch.zeros(self.Bx * H * W, self.nch, dtype=torch.float32, device=dev)
+        self.c0 = sum(a.splits[:stage]) if (a.use_split_head and a.use_spade) else 0
+        self.c1 = sum(a.splits[:stage + 1]) if a.use_split_head else a.in_channels
+        self.spade_on = a.use_spade and self.c0 > 0
+        self.taps = {}
+        # names of every ResBlock in forward order (for the concatenated emb_layers projection)
+        self.res_names = [blk.prefix for grp in (a.input_blocks + [a.middle] + a.output_blocks) for blk in grp
+                          if blk.kind == "res"]
+        self.res_cout = [blk.cout for grp in (a.input_blocks + [a.middle] + a.output_blocks) for blk in grp
+                         if blk.kind == "res"]
+        self.res_off = np.concatenate([[0], np.cumsum(self.res_cout)]).astype(int)
+        self.E = b.persistent_f32(temb_rows, int(self.res_off[-1]))
+        self.kv = {}        # ST prefix -> (k operand [Bx*nctx][C], vT operand [Bx][C][nctx_pad])
+        self.spade = {}     # SPADE module prefix -> (gamma F32-like, beta)
+        self.pre = self._build_pre()
+        self.step = self._build_step()
+
+    # ------------------------------------------------------------------------------------------
+    class _T:  # persistent f32 tensor wrapper with the F32 interface
+        def __init__(self, t):
+            self.t = t
+            self.rows, self.C = t.shape[0], t.shape[1]
+
+        @property
+        def ptr(self):
+            return self.t.data_ptr()
+
+        def free(self):
+            pass
+
+    def _pack_x(self, c0, c1):
+        """operand [Bx*HW][32] of latent channels [c0, c1) (replicated xrep times)."""
+        b, HW = self.b, self.H * self.W
+        o = b.op(self.Bx * HW, rup(c1 - c0, 32))
+        for r in range(self.xrep):
+            b.prog.emit("FRIDO_OP_PACK", src=self.x_state.data_ptr(), B=self.B, HW=HW, Csrc=self.Ctot, c0=c0,
+                        Cuse=c1 - c0, Cpad=o.K, nchw=0, scale=1.0, nsplit=b.nsplit,
+                        out_op=o.ptr + 2 * r * self.B * HW * o.K, out_lo=o.lo)
+        return o
+
+    def _build_pre(self):
+        b, a = self.b, self.a
+        prog = b.new_prog()
+        mc, te = a.model_channels, a.time_embed_dim
+        # ---- timestep / stage embedding table (util.py:151-171, pyunet.py:560-565,882-896) ----
+        n = self.temb_rows
+        sin = b.f32(n, mc)
+        prog.emit("FRIDO_OP_TIME_EMB", t=self.t_dev.data_ptr(), n=n, dim=mc, max_period=10000.0, out=sin.ptr)
+        sin_op = b.to_operand(sin)
+        sin.free()
+        h1 = b.linear(sin_op, "time_embed.0", act=ACT_SILU, out="op")
+        sin_op.free()
+        bias2 = b.w["time_embed.2.bias"].float()
+        if a.num_stage > 1:
+            bias2 = bias2 + b.w["stage_emb.weight"][self.stage].float()
+        bias2 = bias2.contiguous()
+        b._persist.append(bias2)
+        semb = b.linear(h1, "time_embed.2", bias_ptr=bias2.data_ptr(), act=ACT_SILU, out="op")   # SiLU(emb)
+        h1.free()
+        wcat = b.cat_lin_weight("emb_cat", [f"{p}.emb_layers.1.weight" for p in self.res_names])
+        bcat = torch.cat([b.w[f"{p}.emb_layers.1.bias"].float() for p in self.res_names]).contiguous()
+        b._persist.append(bcat)
+        b.linear(semb, None, wop=wcat, bias_ptr=bcat.data_ptr(), out=("f32", self._T(self.E)))
+        semb.free()
+        # ---- cross-attention K / V^T of the context (attention.py:175-176), once per sample ----
+        ctx_op = b.pack(self.ctx_in.data_ptr(), 1, self.Bx * self.nctx, a.context_dim, 0, a.context_dim)
+        for grp in a.input_blocks + [a.middle] + a.output_blocks:
+            for blk in grp:
+                if blk.kind != "st":
+                    continue
+                t = f"{blk.prefix}.transformer_blocks.0.attn2"
+                C = blk.cin
+                k = b.persistent_op(self.Bx * self.nctx, C, zero=False)
+                b.linear(ctx_op, t + ".to_k", bias=False, out=("op", k))
+                vT = b.v_transposed(ctx_op, a.context_dim, b.lin_weight(t + ".to_v.weight"), self.Bx, self.nctx, C)
+                self.kv[blk.prefix] = (k, vT)
+        ctx_op.free()
+        # ---- SPADE conditioning (spade_norm.py:44-60), timestep-invariant within a stage ----
+        if self.spade_on:
+            HW = self.H * self.W
+            xc = self._pack_x(0, self.c0)
+            hc = b.conv(xc, self.Bx, self.H, self.W, f"pre_input_cond_blocks.{self.stage - 1}.0", out="op")
+            xc.free()
+            for name, C, lvl in self._spade_sites():
+                Hl, Wl = self.H >> lvl, self.W >> lvl
+                actv = b.conv(hc, self.Bx, self.H, self.W, name + ".mlp_shared.0", dn=lvl, act=ACT_RELU, out="op")
+                g = self._T(b.persistent_f32(self.Bx * Hl * Wl, C))
+                be = self._T(b.persistent_f32(self.Bx * Hl * Wl, C))
+                b.conv(actv, self.Bx, Hl, Wl, name + ".mlp_gamma", out=("f32", g))
+                b.conv(actv, self.Bx, Hl, Wl, name + ".mlp_beta", out=("f32", be))
+                actv.free()
+                self.spade[name] = (g, be)
+            hc.free()
+        return prog
+
+    def _spade_sites(self):
+        """(SPADE module prefix, channels, resolution level) for every SPADE instance in forward order."""
+        a = self.a
+        out, lvl = [], 0
+        cat_in = {}
+        for grp in a.input_blocks:
+            for blk in grp:
+                if blk.kind == "res":
+                    out += [(blk.prefix + ".in_layers.0", blk.cin, lvl), (blk.prefix + ".out_layers.0", blk.cout, lvl)]
+                elif blk.kind == "st":
+                    out.append((blk.prefix + ".norm", blk.cin, lvl))
+                elif blk.kind == "down":
+                    lvl += 1
+        for blk in a.middle:
+            if blk.kind == "res":
+                out += [(blk.prefix + ".in_layers.0", blk.cin, lvl), (blk.prefix + ".out_layers.0", blk.cout, lvl)]
+            else:
+                out.append((blk.prefix + ".norm", blk.cin, lvl))
+        for grp in a.output_blocks:
+            for blk in grp:
+                if blk.kind == "res":
+                    out += [(blk.prefix + ".in_layers.0", blk.cin, lvl), (blk.prefix + ".out_layers.0", blk.cout, lvl)]
+                elif blk.kind == "st":
+                    out.append((blk.prefix + ".norm", blk.cin, lvl))
+                elif blk.kind == "up":
+                    lvl -= 1
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _norm(self, x1, x2, HW, name, eps, act, want_raw=False):
+        """GroupNorm32 / Normalize, SPADE-wrapped when the config says so (pyunet.py:209,233; attention.py:260)."""
+        b = self.b
+        if self.a.use_spade:
+            g, be = self.spade.get(name, (None, None))
+            return b.groupnorm(x1, x2, self.Bx, HW, name + ".param_free_norm", eps, gamma=g, beta=be, act=act,
+                               want_raw=want_raw)
+        return b.groupnorm(x1, x2, self.Bx, HW, name, eps, act=act, want_raw=want_raw)
+
+    def _rowvec(self, ridx):
+        HW_all = None
+        d = dict(ptr=self.E.data_ptr() + 4 * int(self.res_off[ridx]), ld=int(self.res_off[-1]))
+        if self.per_sample_t:
+            d["rows_per_vec"] = None     # filled by caller (HW at that resolution)
+        else:
+            d["rows_per_vec"] = 1 << 30  # every row uses the row selected by the step counter
+            d["step"] = self.step_ptr
+        return d
+
+    def _res_block(self, blk, x1, x2, h, w, ridx):
+        """pyunet.py:262-300.  x1 (+x2 = skip tensor, virtual concat).  Returns F32 [Bx*h*w][cout]."""
+        b, HW = self.b, h * w
+        pre = blk.prefix
+        has_skip = (pre + ".skip_connection.weight") in b.w
+        a1, raw = self._norm(x1, x2, HW, pre + ".in_layers.0", 1e-5, ACT_SILU, want_raw=has_skip)
+        rv = self._rowvec(ridx)
+        if rv["rows_per_vec"] is None:
+            rv["rows_per_vec"] = HW
+        hmid = b.conv(a1, self.Bx, h, w, pre + ".in_layers.2", rowvec=rv)
+        a1.free()
+        a2, _ = self._norm(hmid, None, HW, pre + ".out_layers.0", 1e-5, ACT_SILU)
+        hmid.free()
+        if has_skip:
+            res = b.linear(raw, pre + ".skip_connection")
+            raw.free()
+            out = b.conv(a2, self.Bx, h, w, pre + ".out_layers.3", residual=res, out=("f32", res))
+        else:
+            assert x2 is None
+            out = b.conv(a2, self.Bx, h, w, pre + ".out_layers.3", residual=x1)
+        a2.free()
+        return out
+
+    def _spatial_transformer(self, blk, x, h, w):
+        """attention.py:289-326 with BasicTransformerBlock._forward (222-227), single head d = C."""
+        b, HW, C, Bx = self.b, h * w, blk.cin, self.Bx
+        pre = blk.prefix
+        t = pre + ".transformer_blocks.0"
+        a0, _ = self._norm(x, None, HW, pre + ".norm", 1e-6, ACT_NONE)
+        hcur = b.linear(a0, pre + ".proj_in")
+        a0.free()
+        # --- self-attention
+        n1 = b.layernorm(hcur, t + ".norm1")
+        wqk = b.cat_lin_weight(("qk", t), [t + ".attn1.to_q.weight", t + ".attn1.to_k.weight"])
+        qk = b.op(Bx * HW, 2 * C)
+        b.linear(n1, None, wop=wqk, bias=False, out=("op", qk))
+        Np = rup(HW, 32)
+        if (C, HW) not in self._vt_self:
+            self._vt_self[(C, HW)] = b.persistent_op(C, Np, batch=Bx, zero=True)
+        vT = self._vt_self[(C, HW)]
+        b.v_transposed(n1, C, b.lin_weight(t + ".attn1.to_v.weight"), Bx, HW, C, out=vT)
+        n1.free()
+        o = b.attention(qk, 2 * C, qk, 2 * C, vT, Bx, HW, HW, C, q_off=0, k_off=C)
+        qk.free()
+        h2 = b.linear(o, t + ".attn1.to_out.0", residual=hcur)
+        o.free()
+        hcur.free()
+        # --- cross-attention (K, V^T cached per sample)
+        n2 = b.layernorm(h2, t + ".norm2")
+        q2 = b.linear(n2, t + ".attn2.to_q", bias=False, out="op")
+        n2.free()
+        kc, vTc = self.kv[pre]
+        o2 = b.attention(q2, C, kc, C, vTc, Bx, HW, self.nctx, C)
+        q2.free()
+        h3 = b.linear(o2, t + ".attn2.to_out.0", residual=h2)
+        o2.free()
+        h2.free()
+        # --- GEGLU feed-forward (attention.py:37-64)
+        n3 = b.layernorm(h3, t + ".norm3")
+        g = b.linear(n3, t + ".ff.net.0.proj")
+        n3.free()
+        gg = b.geglu(g, 4 * C)
+        g.free()
+        h4 = b.linear(gg, t + ".ff.net.2", residual=h3, out="op")
+        gg.free()
+        h3.free()
+        out = b.linear(h4, pre + ".proj_out", residual=x)
+        h4.free()
+        return out
+
+    def _build_step(self):
+        b, a = self.b, self.a
+        prog = b.new_prog()
+        self._vt_self = {}
+        H, W = self.H, self.W
+        s = self.stage
+        xin = self._pack_x(self.c0, self.c1)
+        head = f"pre_input_blocks.{s}.0" if a.use_split_head else "input_blocks.0.0"
+        hcur = b.conv(xin, self.Bx, H, W, head)
+        xin.free()
+        hs = [(hcur, H, W)]
+        h, w = H, W
+        ridx = 0
+        owned = None   # current tensor if it is NOT on the skip stack (must be freed by us)
+        for grp in a.input_blocks:
+            cur = hs[-1][0]
+            first = True
+            for blk in grp:
+                if blk.kind == "res":
+                    nxt = self._res_block(blk, cur, None, h, w, ridx)
+                    ridx += 1
+                elif blk.kind == "st":
+                    nxt = self._spatial_transformer(blk, cur, h, w)
+                elif blk.kind == "down":
+                    xo = b.to_operand(cur)
+                    nxt = b.conv(xo, self.Bx, h, w, blk.prefix + ".op", stride=2, pad=1)
+                    xo.free()
+                    h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+                if not first:
+                    cur.free()      # intermediate inside the group (not a skip)
+                cur, first = nxt, False
+            hs.append((cur, h, w))
+        cur = hs[-1][0]
+        mid_in = cur
+        for i, blk in enumerate(a.middle):
+            if blk.kind == "res":
+                nxt = self._res_block(blk, cur, None, h, w, ridx)
+                ridx += 1
+            else:
+                nxt = self._spatial_transformer(blk, cur, h, w)
+            if cur is not mid_in:
+                cur.free()
+            cur = nxt
+        self._tap("mid", cur, h, w)
+        for grp in a.output_blocks:
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (h, w)
+            first = True
+            for blk in grp:
+                if blk.kind == "res":
+                    nxt = self._res_block(blk, cur, skip if first else None, h, w, ridx)
+                    ridx += 1
+                elif blk.kind == "st":
+                    nxt = self._spatial_transformer(blk, cur, h, w)
+                elif blk.kind == "up":
+                    xo = b.to_operand(cur)
+                    nxt = b.conv(xo, self.Bx, h, w, blk.prefix + ".conv", up=1)
+                    xo.free()
+                    h, w = h * 2, w * 2
+                cur.free()
+                if first:
+                    skip.free()
+                cur, first = nxt, False
+        assert not hs
+        o = f"out.{s}" if a.use_split_head else "out"
+        ao, _ = b.groupnorm(cur, None, self.Bx, h * w, o + ".0", 1e-5, act=ACT_SILU)
+        cur.free()
+        b.conv(ao, self.Bx, h, w, o + ".2", out=("f32", self._T(self.eps)))
+        ao.free()
+        return prog
+
+    def _tap(self, name, t, h, w):
+        pass
+
+    # ------------------------------------------------------------------------------------------
+    def set_context(self, ctx):
+        """ctx: device f32 [Bx][nctx][context_dim]."""
+        self.ctx_in.copy_(ctx)
+
+    def set_timesteps(self, t):
+        self.t_dev.copy_(t)

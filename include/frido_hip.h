@@ -164,6 +164,7 @@ typedef struct FridoSamplerStep {
     const float* coef; const int32_t* step; int32_t coef_row_offset;
     const float* noise; int64_t noise_stride; int32_t noise_C, noise_c0;
     uint64_t seed; int64_t sample0; int32_t rng_stream;
+    const int64_t* rng_dev;      /* optional device {seed, sample0}: overrides the two fields above (graph replay) */
     float temperature;
     float* x_out;                /* where x' goes (may alias x) */
     float* pred_x0;              /* optional [B][HW][Cx] */
@@ -181,6 +182,11 @@ typedef struct FridoRandn {
     float* dst; int64_t n; int64_t per_sample; uint64_t seed; int64_t sample0; int32_t rng_stream;
 } FridoRandn;
 
+/* Sinusoidal timestep embedding (frido/modules/diffusionmodules/util.py:151-171):
+ * out[i][0:half] = cos(t_i * f_k), out[i][half:2*half] = sin(t_i * f_k), f_k = exp(-ln(max_period) * k / half),
+ * all in fp32 like the reference; t is int64 (DDPM indices). */
+typedef struct FridoTimeEmb { const int64_t* t; int32_t n, dim; float max_period; float* out; } FridoTimeEmb;
+
 /* step counter update: *step += delta (one thread). */
 typedef struct FridoStepAdd { int32_t* step; int32_t delta; } FridoStepAdd;
 
@@ -190,7 +196,7 @@ typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -200,7 +206,7 @@ typedef struct FridoOp {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill;
+        FridoFill fill; FridoTimeEmb time_emb;
         char _size[320];
     } u;
 } FridoOp;
@@ -220,6 +226,7 @@ int frido_handoff(const FridoHandoff* d, frido_stream_t s);
 int frido_randn(const FridoRandn* d, frido_stream_t s);
 int frido_step_add(const FridoStepAdd* d, frido_stream_t s);
 int frido_fill(const FridoFill* d, frido_stream_t s);
+int frido_time_emb(const FridoTimeEmb* d, frido_stream_t s);
 
 /* ---- native executor: run / capture a whole program ---- */
 int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);
@@ -234,6 +241,9 @@ int frido_event_create(void** ev);
 int frido_event_record(void* ev, frido_stream_t s);
 int frido_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int frido_event_destroy(void* ev);
+
+/* one-time initialisation (kernel attributes); safe to call repeatedly, must precede graph capture */
+int frido_init(void);
 
 /* ---- introspection ---- */
 int frido_abi_version(void);

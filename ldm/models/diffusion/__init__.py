@@ -1,0 +1,1 @@
+"""Import-path alias package: the reference's config `target:` strings resolve to frido_amd classes."""

@@ -1,0 +1,177 @@
+"""Model-level parity on the MI355X: the HIP path behind the reference's class API against (a) the
+golden fixtures captured from the reference itself and (b) the oracle on the same seeded inputs.
+
+Precision: bf16x3 (fp32-emulating MFMA path).  Stated tolerances, relative to the output's max-abs:
+  single denoiser forward     2e-4      multi-step sampler latents   1e-3
+  VQGAN decode (same codes)   2e-4      decoded pixels end-to-end    1e-3 abs (north star), code flips reported
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import golden, synth_sd, unet_holder, vq_holder  # noqa: E402
+from golden_cfg import (UNET_SMALL, UNET_SMALL3, UNET_FULL, VQ_SMALL, VQ_SMALL3, VQ_FULL, BERT_SMALL, frido_cfg)  # noqa: E402
+from frido_amd.synth import fill_module  # noqa: E402
+
+
+def _rel(got, ref):
+    ref = torch.as_tensor(ref).double()
+    return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max())
+
+
+def _unet(cfg):
+    from frido_amd.models import PyUNetModel
+    m = PyUNetModel(**cfg)
+    fill_module(m, "model.diffusion_model.")
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name,cfg", [("unet_small", UNET_SMALL), ("unet_small3", UNET_SMALL3)])
+def test_unet_forward_matches_reference_golden(name, cfg):
+    g = golden(name)
+    m = _unet(cfg)
+    x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    splits = cfg["split_embed_dim_list"]
+    for s in range(cfg["num_stage"]):
+        e = m(x[:, :sum(splits[:s + 1])].contiguous(), torch.from_numpy(g[f"t_{s}"]).cuda(), context=ctx, stage=s)
+        assert e.shape == g[f"eps_{s}"].shape
+        assert _rel(e, g[f"eps_{s}"]) < 2e-4, (name, s)
+
+
+def test_unet_forward_bf16_mode_within_bf16_tolerance():
+    g = golden("unet_small")
+    from frido_amd.models import PyUNetModel
+    m = fill_module(PyUNetModel(**UNET_SMALL, precision="bf16"), "model.diffusion_model.").cuda()
+    x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    e = m(x, torch.from_numpy(g["t_1"]).cuda(), context=ctx, stage=1)
+    assert _rel(e, g["eps_1"]) < 5e-2
+
+
+def test_unet_full_width_forward_matches_reference_golden():
+    g = golden("unet_full")
+    m = _unet(UNET_FULL)
+    x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    for s in range(2):
+        e = m(x[:, :3 * (s + 1)].contiguous(), torch.from_numpy(g[f"t_{s}"]).cuda(), context=ctx, stage=s)
+        assert _rel(e, g[f"eps_{s}"]) < 2e-4, s
+
+
+def test_no_cpu_fallback():
+    from frido_amd.models import PyUNetModel
+    from frido_amd._lib import FridoHipError
+    m = PyUNetModel(**UNET_SMALL)
+    with pytest.raises(FridoHipError):
+        m(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 5, 64), stage=0)
+
+
+def _vq(cfg):
+    from frido_amd.models import VQModelInterface
+    m = VQModelInterface(**cfg, lossconfig=dict(target="taming.modules.losses.DummyLoss"))
+    fill_module(m, "first_stage_model.")
+    return m.cuda().eval()
+
+
+def test_vq_decode_matches_reference_golden():
+    g = golden("vq_small")
+    m = _vq(VQ_SMALL)
+    dec, code = m.decode(torch.from_numpy(g["h"]).cuda(), return_code=True)
+    code = np.asarray(code)
+    flips = (code != g["code"]).mean()
+    assert flips < 2e-3
+    if flips == 0:
+        assert _rel(dec, g["dec"]) < 2e-4
+
+
+def test_vq_full_width_decode_matches_reference_golden():
+    g = golden("vq_full")
+    m = _vq(VQ_FULL)
+    dec, code = m.decode(torch.from_numpy(g["h"]).cuda(), return_code=True)
+    flips = (np.asarray(code) != g["code"]).mean()
+    assert flips < 1e-3
+    ss = int(g["subsample"])
+    got = dec[:, :, ::ss, ::ss]
+    if flips == 0:
+        assert _rel(got, g["dec"]) < 3e-4
+        assert abs(float(dec.double().sum()) - float(g["dec_sum"])) < 2e-4 * float(g["dec_abs_sum"])
+
+
+def _frido(ucfg, vcfg):
+    from frido_amd.models import instantiate_from_config
+    cfg = frido_cfg(ucfg, vcfg, BERT_SMALL)
+    cfg["cond_stage_config"] = "__is_unconditional__"   # conditioning tensors come from the golden (cond stage = SURVEY §8f)
+    cfg["conditioning_key"] = "crossattn"
+    m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    fill_module(m.model, "model.")
+    fill_module(m.first_stage_model, "first_stage_model.")
+    m.scale_factor.copy_(torch.tensor([0.9, 1.1, 1.05][:len(vcfg["embed_dim"])]))
+    return m.cuda().eval()
+
+
+class _Tape:
+    def __init__(self, flat):
+        self.t, self.pos = torch.from_numpy(np.asarray(flat, dtype=np.float32)), 0
+
+    def __call__(self, shape):
+        n = int(np.prod(shape))
+        out = self.t[self.pos:self.pos + n].reshape(shape).clone()
+        assert out.numel() == n
+        self.pos += n
+        return out
+
+
+@pytest.mark.parametrize("name,ucfg,vcfg", [("sampler_small", UNET_SMALL, VQ_SMALL), ("sampler_small3", UNET_SMALL3, VQ_SMALL3)])
+@pytest.mark.parametrize("run", ["ddim_eta1", "ddim_eta0_cfg", "plms", "plms_cfg"])
+def test_sampler_matches_reference_golden(name, ucfg, vcfg, run):
+    from frido.models.diffusion.ddim import DDIMSampler
+    from frido.models.diffusion.plms import PLMSSampler
+    g = golden(name)
+    model = _frido(ucfg, vcfg)
+    c = torch.from_numpy(g["c"]).cuda()
+    uc = torch.zeros_like(c)
+    S, eta, scale, lev = g[f"{run}_args"]
+    cls = PLMSSampler if run.startswith("plms") else DDIMSampler
+    B = c.shape[0]
+    tape = _Tape(g[f"{run}_noise"])
+    samples, inter = cls(model).sample(S=int(S), batch_size=B, shape=(ucfg["in_channels"], 16, 16), conditioning=c,
+                                       num_stage=ucfg["num_stage"], eta=float(eta), verbose=False, log_every_t=int(lev),
+                                       unconditional_guidance_scale=float(scale),
+                                       unconditional_conditioning=uc if scale != 1.0 else None, noise=tape)
+    assert tape.pos == tape.t.numel(), "noise stream not consumed like the reference"
+    assert _rel(samples, g[f"{run}_samples"]) < 1e-3
+    assert len(inter["x_inter"]) == int(g[f"{run}_nx"])
+    assert _rel(inter["x_inter"][-1], g[f"{run}_x_inter_last"]) < 1e-3
+    assert _rel(inter["pred_x0"][1], g[f"{run}_pred_x0_1"]) < 1e-3
+    img, code = model.decode_first_stage(samples, return_code=True)
+    ref_img = torch.from_numpy(g[f"{run}_img"])
+    # north-star criterion: <= 1e-3 max-abs on decoded pixels — holds wherever the VQ codes agree
+    err = (img.cpu() - ref_img).abs().amax(dim=1)
+    frac_bad = float((err > 1e-3).float().mean())
+    assert frac_bad < 0.02, frac_bad
+
+
+def test_sampler_torch_seed_reproduces_reference_noise_stream():
+    from frido.models.diffusion.ddim import DDIMSampler
+    g = golden("sampler_small")
+    model = _frido(UNET_SMALL, VQ_SMALL)
+    c = torch.from_numpy(g["c"]).cuda()
+    torch.manual_seed(23)    # what tests/golden/make_golden.py seeded the reference with
+    samples, _ = DDIMSampler(model).sample(S=4, batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=1.0,
+                                           verbose=False, log_every_t=2, noise="torch")
+    assert _rel(samples, g["ddim_eta1_samples"]) < 1e-3
+
+
+def test_sampler_philox_graph_replay_is_deterministic_and_shard_invariant():
+    from frido.models.diffusion.ddim import DDIMSampler
+    g = golden("sampler_small")
+    model = _frido(UNET_SMALL, VQ_SMALL)
+    c = torch.from_numpy(g["c"]).cuda()
+    kw = dict(S=4, shape=(6, 16, 16), num_stage=2, eta=1.0, verbose=False, noise="philox", seed=99)
+    a, _ = DDIMSampler(model).sample(batch_size=2, conditioning=c, **kw)
+    b, _ = DDIMSampler(model).sample(batch_size=2, conditioning=c, **kw)
+    assert torch.equal(a, b)
+    # rank 1 of a 2-way shard owns global sample 1: same result as inside the full batch
+    s1, _ = DDIMSampler(model).sample(batch_size=1, conditioning=c[1:2].contiguous(), sample0=1, **kw)
+    assert _rel(s1, a[1:2].cpu()) < 1e-3
+    assert torch.isfinite(a).all() and float(a.std()) > 0.1
