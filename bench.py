@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec @ DDIM-200, COCO layout2img 256x256 (BASELINE.json), on N MI355X.
+
+One "step" = one full pass of the hot path over one per-GPU batch of synthetic inputs: x_T draw, the
+2-stage DDIM-200 loop (400 denoiser forwards, hipGraph replays), stage hand-off, MS-VQGAN decode, and (N>1)
+the RCCL all-gather of decoded images.  Inputs (context) are resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the driver contract): value is whole-job images/s; "roofline" is measured
+live with HIP events on the launch stream around every op of one denoiser forward; "cpu_baseline" times the
+oracle (CPU restatement of the reference) on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from frido_amd import configs, synth  # noqa: E402
+
+
+def build_model(precision, device):
+    from frido_amd.models import instantiate_from_config
+    cfg = configs.frido_cfg(configs.UNET_F8F4, configs.VQ_F8F4, configs.BERT_FULL)
+    cfg["cond_stage_config"] = "__is_unconditional__"    # synthetic context tensors stand in for the cond stage (§8f)
+    cfg["conditioning_key"] = "crossattn"
+    cfg["use_ema"] = False
+    cfg["unet_config"]["params"]["precision"] = precision
+    cfg["first_stage_config"]["params"]["precision"] = precision
+    m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    synth.fill_module(m.model, "model.")
+    synth.fill_module(m.first_stage_model, "first_stage_model.")
+    return m.to(device).eval()
+
+
+def gemm_roofline(eng, stream_ptr, precision):
+    """Per-op HIP-event timing of one stage-1 denoiser forward; aggregates the MFMA implicit-GEMM launches."""
+    from frido_amd import _lib
+    prog = eng.stages[-1].step
+    eng.step.zero_()                          # rewind the device step counter (it indexes the timestep table)
+    prog.run(stream_ptr)                      # warm
+    ms = prog.run_timed(stream_ptr)
+    k_gemm = _lib.OP_KINDS["FRIDO_OP_GEMM"]
+    t_gemm = flops = n_gemm = 0
+    conv_t = conv_f = 0.0
+    for (kind, st), t in zip(prog.ops, ms):
+        if kind == k_gemm:
+            f = 2.0 * st.M * st.N * st.K * st.batch
+            t_gemm += t
+            flops += f
+            n_gemm += 1
+            if st.conv:
+                conv_t += t
+                conv_f += f
+    total = sum(ms)
+    achieved = flops / (t_gemm * 1e-3) / 1e12
+    peak = 2500.0
+    return dict(bound="mfma", kernel="igemm_kernel (implicit-GEMM conv3x3 + GEMM, v_mfma_f32_16x16x32_bf16)",
+                achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+                launches=n_gemm, avg_launch_us=round(1e3 * t_gemm / n_gemm, 2),
+                alg_gflop_per_launch=round(flops / n_gemm / 1e9, 3),
+                conv_tflops=round(conv_f / (conv_t * 1e-3) / 1e12, 2) if conv_t else None,
+                gemm_share_of_forward=round(t_gemm / total, 4), forward_ms=round(total, 3),
+                mfma_passes=3 if precision == "bf16x3" else 1)
+
+
+def cpu_baseline(threads):
+    """Oracle (CPU restatement of the reference, fp32) on a bounded sample: B=1, two denoiser forwards per stage
+    and one decode, extrapolated linearly to DDIM-200 (cost is linear in the step count)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.unet import unet_forward
+    from oracle.vqgan import vq_decode
+    from frido_amd.models import PyUNetModel, VQModelInterface
+    torch.set_num_threads(threads)
+    u = PyUNetModel(**configs.UNET_F8F4)
+    usd = {"model.diffusion_model." + k: torch.from_numpy(synth.fill_tensor("model.diffusion_model." + k, v.shape))
+           for k, v in u.state_dict().items()}
+    v = VQModelInterface(**configs.VQ_F8F4, lossconfig=dict(target="taming.modules.losses.DummyLoss"))
+    vsd = {"first_stage_model." + k: torch.from_numpy(synth.fill_tensor("first_stage_model." + k, t.shape))
+           for k, t in v.state_dict().items()}
+    x = torch.from_numpy(synth.seeded_normal("cpu:x", (1, 6, 64, 64)))
+    ctx = torch.from_numpy(synth.seeded_normal("cpu:ctx", (1, 26, 640)))
+    t = torch.tensor([501])
+    ts = []
+    for s in (0, 1):
+        xin = x[:, :3 * (s + 1)]
+        unet_forward(usd, configs.UNET_F8F4, xin, t, ctx, s)          # warm
+        t0 = time.perf_counter()
+        for _ in range(2):
+            unet_forward(usd, configs.UNET_F8F4, xin, t, ctx, s)
+        ts.append((time.perf_counter() - t0) / 2)
+    t0 = time.perf_counter()
+    vq_decode(vsd, configs.VQ_F8F4, x)
+    td = time.perf_counter() - t0
+    per_image = 200 * ts[0] + 200 * ts[1] + td
+    return dict(value=round(1.0 / per_image, 6), unit="images/s", cores=threads, kind="port",
+                sample=f"oracle fp32, B=1: 2 timed denoiser forwards per stage ({ts[0]:.3f}s / {ts[1]:.3f}s) + 1 decode "
+                       f"({td:.2f}s), extrapolated to 2x200 forwards + decode")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config 2: 16)")
+    ap.add_argument("--ddim-steps", type=int, default=200)
+    ap.add_argument("--precision", default=os.environ.get("FRIDO_PRECISION", "bf16"), choices=["bf16", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from frido_amd.pipeline import sample_images, shard_range
+    model = build_model(args.precision, dev)
+    B = args.batch
+    total = B * world
+    lo, hi = shard_range(total, rank, world)
+    ctx_all = synth.seeded_normal("bench:ctx", (total, 26, 640))
+    ctx = torch.from_numpy(ctx_all[lo:hi]).to(dev)
+
+    def one_step(k):
+        return sample_images(model, ctx, S=args.ddim_steps, eta=1.0, seed=1000 + k, sample0=lo, noise="philox", total=total)
+
+    for k in range(args.warmup):
+        one_step(k)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        img = one_step(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert img.shape == (total, 3, 256, 256) and bool(torch.isfinite(img).all())
+
+    if rank == 0:
+        rt = model.model.diffusion_model.runtime()
+        eng = next(iter(rt._sampler_engines.values()))
+        roof = gemm_roofline(eng, torch.cuda.current_stream().cuda_stream, args.precision)
+        out = {
+            "metric": "images/sec @ DDIM-200, COCO layout2img 256x256", "value": round(total * args.steps / dt, 4),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-emulating, fp32 accumulate)",
+            "data": "synthetic (random-init weights from the deterministic filler, N(0,1) context, Philox x_T/noise)",
+            "config": {"workload": f"layout2i f8f4 (configs/frido/layout2i/frido_f8f4_coco_seg.yaml), per-GPU batch {B}, "
+                                   f"DDIM-{args.ddim_steps} eta=1.0 x 2 stages + MS-VQGAN decode"
+                                   + (", RCCL all-gather of decoded images" if world > 1 else ""),
+                       "global_batch": total, "denoiser_forwards_per_step": 2 * args.ddim_steps, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_threads or os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

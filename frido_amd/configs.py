@@ -1,0 +1,45 @@
+"""Model configurations as plain dicts.
+
+UNET_F8F4 / VQ_F8F4 restate configs/frido/layout2i/frido_f8f4_coco_seg.yaml:21-77 of the reference (BASELINE.json
+configs 1, 2, 4); UNET_F16F8 / VQ_F16F8 restate configs/frido/t2i/frido_f16f8_coco_clip.yaml (config 3).
+"""
+import copy
+
+UNET_F8F4 = dict(
+    use_split_head=True, split_embed_dim_list=[3, 3], use_SPADE_norm=True, image_size=64,
+    in_channels=6, out_channels=6, model_channels=192, attention_resolutions=[8, 4, 2],
+    num_res_blocks=2, channel_mult=[1, 2, 3, 5], num_head_channels=32,
+    use_spatial_transformer=True, transformer_depth=1, context_dim=640, num_stage=2)
+
+VQ_F8F4 = dict(
+    embed_dim=[3, 3], n_embed=[4096, 4096],
+    edconfig=dict(multiscale=2, double_z=False, z_channels=[3, 3], resolution=256, in_channels=3,
+                  out_ch=3, ch=128, ch_mult=[1, 1, 2, 4], num_res_blocks=2, attn_resolutions=[64],
+                  dropout=0.0),
+    ddconfig=dict(double_z=False, z_channels=6, resolution=256, in_channels=3, out_ch=3, ch=128,
+                  ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[64], dropout=0.0))
+
+UNET_F16F8 = dict(
+    use_split_head=True, split_embed_dim_list=[4, 4], use_SPADE_norm=True, image_size=32,
+    in_channels=8, out_channels=8, model_channels=192, attention_resolutions=[8, 4, 2],
+    num_res_blocks=2, channel_mult=[1, 2, 3, 5], num_head_channels=32,
+    use_spatial_transformer=True, transformer_depth=1, context_dim=768, num_stage=2)
+
+BERT_FULL = dict(n_embed=640, n_layer=32, max_seq_len=96, use_tokenizer=False)
+
+
+def frido_cfg(ucfg, vcfg, bcfg,
+              unet_target="frido.modules.diffusionmodules.pyunet.PyUNetModel",
+              vq_target="taming.models.msvqgan.VQModelInterface",
+              bert_target="frido.modules.encoders.modules.BERTEmbedder"):
+    """kwargs for FridoDiffusion(...) mirroring the reference YAML's `model.params`."""
+    return dict(
+        adopted_scale_factor=True, noise_mix_ratio=0.1, first_stage_key="image",
+        cond_stage_key="objects_bbox", linear_start=0.0015, linear_end=0.0155, num_timesteps_cond=1,
+        log_every_t=200, timesteps=1000, loss_type="l1", image_size=ucfg["image_size"],
+        channels=ucfg["in_channels"], cond_stage_trainable=True, conditioning_key="crossattn",
+        scale_by_std=True, monitor="val/loss",
+        unet_config=dict(target=unet_target, params=copy.deepcopy(ucfg)),
+        first_stage_config=dict(target=vq_target, params=dict(
+            copy.deepcopy(vcfg), lossconfig=dict(target="taming.modules.losses.DummyLoss"))),
+        cond_stage_config=dict(target=bert_target, params=copy.deepcopy(bcfg)))

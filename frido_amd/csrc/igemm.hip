@@ -1,40 +1,64 @@
 // Implicit-GEMM on the CDNA4 matrix pipe: C[m][n] = sum_k A[m][k] * B[n][k]  (both K-contiguous bf16).
 //
 //  * one workgroup = 256 threads = 4 waves (2 x 2) computing a BM x BN tile with
-//    v_mfma_f32_16x16x32_bf16; K is walked in BK = 32 steps (one MFMA k-step per LDS tile);
+//    v_mfma_f32_16x16x32_bf16; K is walked in BK = 32 steps (one MFMA k-step per LDS stage);
 //  * A is either a dense operand matrix or an NHWC image gathered on the fly (3x3 / 1x1 conv with
 //    stride, zero padding, nearest x2 up-sampling or 2^k sub-sampling folded into the address);
-//  * tiles are register-staged: the global loads of k-tile t+1 are issued before the MFMAs of tile t
-//    and written to the other LDS buffer afterwards (one barrier per k-tile);
-//  * LDS rows are 64 B (32 bf16); the 16-B slot q of row r lives at slot q ^ ((4 - (r>>2)) & 3), which
-//    makes both the ds_write_b128 staging stores and the ds_read_b128 fragment loads conflict-free
-//    for the 16x16x32 fragment layout (MI355X_MICROARCH.md §LDS lane groups);
+//  * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB = 16 rows x 64 B per wave
+//    instruction) through a D-deep ring of LDS stages: D-1 k-tiles are in flight while one is consumed;
+//    a stage is waited for with a COUNTED s_waitcnt vmcnt(N) and published with one raw s_barrier per
+//    k-tile (loads stay in flight across the barrier); fragment ds_reads are inline asm so that hipcc does
+//    not fence them with vmcnt(0) (cdna_hip_programming.md §5 "Pipelining across barriers", §5.7);
+//  * LDS rows are 64 B (32 bf16); the 16-B slot q of row r lives at slot q ^ ((4 - (r>>2)) & 3): the
+//    LDS-DMA image is lane-linear, so the swizzle is applied to the per-lane SOURCE address and to the
+//    fragment read address (rule 21); it makes the ds_read_b128 fragment loads conflict-free for the
+//    16x16x32 fragment layout (MI355X_MICROARCH.md §LDS lane groups); conv taps that fall into the
+//    zero padding read a 16-byte zero page instead;
 //  * nsplit == 2 ("bf16x3"): operands carry a second bf16 plane with the rounding residual and each
 //    tile product is hi*hi + hi*lo + lo*hi (fp32 accumulate) — ~2^-17 relative error at 3 MFMAs;
-//  * fused epilogue: alpha, bias[n], per-row-group vector (timestep embedding), ReLU/SiLU, residual,
-//    f32 and/or operand (bf16 hi/lo) output.
+//  * fused epilogue: alpha, bias[n], per-row bias, per-row-group vector (timestep embedding), ReLU/SiLU,
+//    residual, f32 and/or operand (bf16 hi/lo) output.
 #include "common.h"
 
 namespace {
 
-struct RowInfo {      // per staged A row (conv mode)
-    int b, oy, ox;
-    bool ok;
+__device__ uint4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int NS>
+struct Geo {
+    static constexpr int D = NS == 1 ? 4 : 3;               // LDS ring depth
+    static constexpr int JA = BM / 64, JB = BN / 64;        // 1-KiB chunks per wave per plane
+    static constexpr int LPT = (JA + JB) * NS;              // LDS-DMA instructions per thread per k-tile
+    static constexpr int PLANE = (BM + BN) * 64;
+    static constexpr int STAGE = NS * PLANE;
+    static constexpr int SMEM = D * STAGE;
 };
 
-__device__ __forceinline__ int swz(int row, int q) { return q ^ ((4 - ((row >> 2) & 3)) & 3); }
-
 template <int BM, int BN, int NS, bool CONV>
-__global__ __launch_bounds__(256) void igemm_kernel(const FridoGemm d) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
+    using G = Geo<BM, BN, NS>;
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int SA = BM * 4 / 256, SB = BN * 4 / 256;      // 16-B slots per thread per plane
-    constexpr int PLANE = (BM + BN) * 64;                    // bytes per plane per buffer
-    constexpr int BUF = NS * PLANE;
+    constexpr int D = G::D, JA = G::JA, JB = G::JB, PLANE = G::PLANE, STAGE = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- block -> tile (XCD-aware: consecutive logical tiles share an A row-panel and an XCD L2) ----
@@ -53,87 +77,104 @@ __global__ __launch_bounds__(256) void igemm_kernel(const FridoGemm d) {
     const frido_bf16* __restrict__ Ab = d.A + (int64_t)z * d.a_bs;
     const frido_bf16* __restrict__ Bb = d.B + (int64_t)z * d.b_bs;
 
-    // ---- per-thread staging assignments ----
-    int64_t a_off[SA];
-    RowInfo a_ri[SA];
-    int a_lds[SA];
+    // ---- LDS-DMA assignments: wave w moves chunks w, w+4, ... ; lane l of a chunk lands at row l>>2, physical
+    //      slot l&3, i.e. it must FETCH logical slot (l&3) ^ swz(row) ----
+    const int lrow = lane >> 2;
+    const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
+    // conv: element offset of tap (0,0) of this row's receptive field + a bit mask of the taps that fall inside
+    // the (logical) input; with resampling folded in (up/dn shifts) the per-tap offsets are tabulated instead
+    int64_t a_off[JA];
+    unsigned a_mask[JA];
+    const bool resample = CONV && (d.up_shift | d.dn_shift) != 0;
+    int a_b[JA], a_oy[JA], a_ox[JA];
 #pragma unroll
-    for (int j = 0; j < SA; ++j) {
-        const int s = t + j * 256, row = s >> 2, q = s & 3;
-        const int m = m0 + row;
-        a_lds[j] = row * 64 + (swz(row, q) << 4);
-        a_ri[j].ok = m < d.M;
+    for (int j = 0; j < JA; ++j) {
+        const int row = (wave + 4 * j) * 16 + lrow;
+        int m = m0 + row;
         if (CONV) {
+            const bool okm = m < d.M;
+            m = okm ? m : 0;
             const int hw = d.Ho * d.Wo;
-            const int mm = a_ri[j].ok ? m : 0;
-            const int b = mm / hw, rem = mm - b * hw;
-            a_ri[j].b = b;
-            a_ri[j].oy = rem / d.Wo;
-            a_ri[j].ox = rem - a_ri[j].oy * d.Wo;
-            a_off[j] = q * 8;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+            a_b[j] = b; a_oy[j] = oy; a_ox[j] = ox;
+            unsigned mask = 0;
+            for (int ty = 0; ty < d.kh; ++ty)
+                for (int tx = 0; tx < d.kw; ++tx) {
+                    const int iy = oy * d.stride + ty - d.pad, ix = ox * d.stride + tx - d.pad;
+                    if (okm && iy >= 0 && iy < d.Hl && ix >= 0 && ix < d.Wl) mask |= 1u << (ty * d.kw + tx);
+                }
+            a_mask[j] = mask;
+            a_off[j] = ((int64_t)(b * d.Hs + oy * d.stride - d.pad) * d.Ws + (ox * d.stride - d.pad)) * d.Cin + lq * 8;
         } else {
-            a_off[j] = (int64_t)(a_ri[j].ok ? m : 0) * d.lda + q * 8;
+            m = m < d.M ? m : d.M - 1;      // rows past M are clamped (their outputs are masked)
+            a_off[j] = (int64_t)m * d.lda + lq * 8;
         }
     }
-    int64_t b_off[SB];
-    int b_lds[SB];
+    int64_t b_off[JB];
 #pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        const int s = t + j * 256, row = s >> 2, q = s & 3;
+    for (int j = 0; j < JB; ++j) {
+        const int row = (wave + 4 * j) * 16 + lrow;
         int n = n0 + row;
         n = n < d.N ? n : d.N - 1;
-        b_off[j] = (int64_t)n * d.ldb + q * 8;
-        b_lds[j] = BM * 64 + row * 64 + (swz(row, q) << 4);
+        b_off[j] = (int64_t)n * d.ldb + lq * 8;
     }
 
     const int nk = d.K >> 5;
-    // conv k-walk state (uniform): channel offset inside the tap, tap coordinates
-    int kc = 0, ky = 0, kx = 0;
+    int kc = 0, ky = 0, kx = 0, tap = 0;   // conv k-walk (uniform): channel offset inside the tap, tap coordinates
+    int64_t tap_off = 0;                   // ((ky * Ws + kx) * Cin + kc): offset of the current k-tile from tap (0,0)
+    const int cin = d.Cin, kw = d.kw, ws = d.Ws;
+    // keep the zero page's address in SGPRs (otherwise hipcc re-loads it from the GOT inside the k-loop)
+    unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
+    asm volatile("" : "+s"(zero_addr));
+    const int64_t a_lo = d.a_lo, b_lo = d.b_lo;
 
-    u32x4 ra[NS][SA], rb[NS][SB];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    auto load_tile = [&](int kt) {
+    auto issue = [&](int kt, int buf) {
+        unsigned char* sb = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < SA; ++j) {
-            bool ok = a_ri[j].ok;
-            int64_t off;
+        for (int j = 0; j < JA; ++j) {
+            const frido_bf16* src;
             if (CONV) {
-                const int iy = a_ri[j].oy * d.stride + ky - d.pad;
-                const int ix = a_ri[j].ox * d.stride + kx - d.pad;
-                ok = ok && iy >= 0 && iy < d.Hl && ix >= 0 && ix < d.Wl;
-                const int sy = (iy >> d.up_shift) << d.dn_shift;
-                const int sx = (ix >> d.up_shift) << d.dn_shift;
-                off = ((int64_t)(a_ri[j].b * d.Hs + sy) * d.Ws + sx) * d.Cin + kc + a_off[j];
-            } else {
-                off = a_off[j] + (int64_t)kt * 32;
-            }
+                const bool ok = (a_mask[j] >> tap) & 1u;
+                int64_t off;
+                if (resample) {   // Upsample / SPADE-resize convs: source pixel = ((iy >> up) << dn, (ix >> up) << dn)
+                    const int iy = a_oy[j] * d.stride + ky - d.pad, ix = a_ox[j] * d.stride + kx - d.pad;
+                    const int sy = (iy >> d.up_shift) << d.dn_shift, sx = (ix >> d.up_shift) << d.dn_shift;
+                    off = ((int64_t)(a_b[j] * d.Hs + sy) * d.Ws + sx) * d.Cin + kc + lq * 8;
+                } else {
+                    off = a_off[j] + tap_off;
+                }
 #pragma unroll
-            for (int p = 0; p < NS; ++p)
-                ra[p][j] = ok ? *reinterpret_cast<const u32x4*>(Ab + (p ? d.a_lo : 0) + off) : zero4;
+                for (int p = 0; p < NS; ++p) {
+                    src = ok ? Ab + (p ? a_lo : 0) + off : reinterpret_cast<const frido_bf16*>(zero_addr);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * 4096), 16, 0, 0);
+                }
+            } else {
+                const int64_t off = a_off[j] + (int64_t)kt * 32;
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    src = Ab + (p ? a_lo : 0) + off;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * 4096), 16, 0, 0);
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
+        for (int j = 0; j < JB; ++j) {
             const int64_t off = b_off[j] + (int64_t)kt * 32;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) rb[p][j] = *reinterpret_cast<const u32x4*>(Bb + (p ? d.b_lo : 0) + off);
+            for (int p = 0; p < NS; ++p)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (p ? b_lo : 0) + off),
+                                                 (lptr_t)(sb + p * PLANE + BM * 64 + j * 4096), 16, 0, 0);
         }
         if (CONV) {   // advance the (tap, channel) walk
             kc += 32;
-            if (kc == d.Cin) {
+            tap_off += 32;
+            if (kc == cin) {
                 kc = 0;
-                if (++kx == d.kw) { kx = 0; ++ky; }
+                ++tap;
+                if (++kx == kw) { kx = 0; ++ky; }
+                tap_off = ((int64_t)ky * ws + kx) * cin;
             }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* base = smem + buf * BUF;
-#pragma unroll
-        for (int p = 0; p < NS; ++p) {
-#pragma unroll
-            for (int j = 0; j < SA; ++j) *reinterpret_cast<u32x4*>(base + p * PLANE + a_lds[j]) = ra[p][j];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) *reinterpret_cast<u32x4*>(base + p * PLANE + b_lds[j]) = rb[p][j];
         }
     };
 
@@ -146,39 +187,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(const FridoGemm d) {
     // fragment addresses: row (lane & 15) of a 16-row MFMA tile, logical slot (lane >> 4)
     const int frow = lane & 15;
     const int fslot = ((lane >> 4) ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4;
-    const int a_frag = (wm * (BM / WM) + frow) * 64 + fslot;
-    const int b_frag = BM * 64 + (wn * (BN / WN) + frow) * 64 + fslot;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * 64 + fslot;
+    const unsigned b_frag = lds0 + BM * 64 + (wn * (BN / WN) + frow) * 64 + fslot;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    // ---- prologue: fill D-1 stages ----
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s)
+        if (s < nk) issue(s, s);
 
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char* base = smem + cur * BUF;
+        // tile kt must have landed: at most the loads of the (D-2) younger tiles may stay in flight
+        if (kt + D - 2 < nk) wait_vmcnt<(D - 2) * G::LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is visible; stage (kt-1)%D is free
+        if (kt + D - 1 < nk) {
+            int nb_ = buf + D - 1;
+            nb_ = nb_ >= D ? nb_ - D : nb_;
+            issue(kt + D - 1, nb_);
+        }
+        const unsigned sa = a_frag + buf * STAGE, sbb = b_frag + buf * STAGE;
         bf16x8 fa[NS][TM];
 #pragma unroll
         for (int p = 0; p < NS; ++p)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[p][i] = *reinterpret_cast<const bf16x8*>(base + p * PLANE + a_frag + i * 16 * 64);
+            for (int i = 0; i < TM; ++i) fa[p][i] = lds_read128(sa + p * PLANE + i * 1024);
+        bf16x8 fb[2][NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) fb[0][p] = lds_read128(sbb + p * PLANE);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            bf16x8 fb[NS];
+            if (j + 1 < TN) {
 #pragma unroll
-            for (int p = 0; p < NS; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(base + p * PLANE + b_frag + j * 16 * 64);
+                for (int p = 0; p < NS; ++p) fb[(j + 1) & 1][p] = lds_read128(sbb + p * PLANE + (j + 1) * 1024);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (NS == 2) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][1], acc[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        buf = buf + 1 == D ? 0 : buf + 1;
     }
 
     // ---- epilogue: lane holds D[row = (lane>>4)*4 + e][col = lane & 15] of each 16x16 tile ----
@@ -211,7 +269,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const FridoGemm d) {
 
 template <int BM, int BN, int NS, bool CONV>
 int set_attr() {
-    constexpr int smem = 2 * NS * (BM + BN) * 64;
+    constexpr int smem = Geo<BM, BN, NS>::SMEM;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         frido_set_error("igemm: cannot set dynamic LDS size %d", smem);
@@ -222,7 +280,7 @@ int set_attr() {
 
 template <int BM, int BN, int NS, bool CONV>
 int launch(const FridoGemm& d, hipStream_t s) {
-    constexpr int smem = 2 * NS * (BM + BN) * 64;
+    constexpr int smem = Geo<BM, BN, NS>::SMEM;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV>), dim3(tiles, d.batch), dim3(256), smem, s, d);
     return frido_check_launch("igemm");
@@ -233,6 +291,9 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
     switch (tile) {
         case 1: return launch<128, 128, NS, CONV>(d, s);
         case 2: return launch<128, 192, NS, CONV>(d, s);
+        case 4: return launch<128, 64, NS, CONV>(d, s);
+        case 5: return launch<64, 192, NS, CONV>(d, s);
+        case 6: return launch<64, 128, NS, CONV>(d, s);
         default: return launch<64, 64, NS, CONV>(d, s);
     }
 }
@@ -252,10 +313,11 @@ int pick_tile(const FridoGemm& d) {
 
 int frido_igemm_init() {
     int rc = 0;
-    rc |= set_attr<128, 128, 1, true>() | set_attr<128, 192, 1, true>() | set_attr<64, 64, 1, true>();
-    rc |= set_attr<128, 128, 1, false>() | set_attr<128, 192, 1, false>() | set_attr<64, 64, 1, false>();
-    rc |= set_attr<128, 128, 2, true>() | set_attr<128, 192, 2, true>() | set_attr<64, 64, 2, true>();
-    rc |= set_attr<128, 128, 2, false>() | set_attr<128, 192, 2, false>() | set_attr<64, 64, 2, false>();
+#define FRIDO_SET_ALL(BM, BN) \
+    rc |= set_attr<BM, BN, 1, true>() | set_attr<BM, BN, 1, false>() | set_attr<BM, BN, 2, true>() | set_attr<BM, BN, 2, false>()
+    FRIDO_SET_ALL(128, 128); FRIDO_SET_ALL(128, 192); FRIDO_SET_ALL(64, 64);
+    FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
+#undef FRIDO_SET_ALL
     return rc ? FRIDO_EHIP : FRIDO_OK;
 }
 

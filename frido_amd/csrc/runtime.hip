@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -76,6 +77,29 @@ extern "C" int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s) {
         }
     }
     return FRIDO_OK;
+}
+
+extern "C" int frido_run_timed(const FridoOp* ops, int32_t n, frido_stream_t s, float* ms) {
+    if (!ops || n <= 0 || !ms) {
+        frido_set_error("frido_run_timed: bad arguments");
+        return FRIDO_EINVAL;
+    }
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return FRIDO_EHIP;
+    int rc = FRIDO_OK;
+    (void)hipEventRecord(ev[0], (hipStream_t)s);
+    for (int32_t i = 0; i < n && rc == FRIDO_OK; ++i) {
+        rc = run_one(ops[i], s);
+        (void)hipEventRecord(ev[i + 1], (hipStream_t)s);
+    }
+    if (rc == FRIDO_OK) {
+        (void)hipEventSynchronize(ev[n]);
+        for (int32_t i = 0; i < n; ++i)
+            if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = FRIDO_EHIP;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 extern "C" int frido_graph_capture(const FridoOp* ops, int32_t n, frido_stream_t s, void** out) {

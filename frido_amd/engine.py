@@ -194,6 +194,10 @@ class Prog:
         if out_op is not None:
             kw.update(out_op=out_op, oo_bs=oo_bs, ldoo=ldoo, oo_lo=oo_lo)
         self.emit("FRIDO_OP_GEMM", **kw)
+        if not tile and self.device.type == "cuda":
+            from . import tune
+            st = self.ops[-1][1]
+            st.tile = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
         self.flops += 2 * M * N * K * batch * (3 if self.nsplit == 2 else 1)
 
     # ---- execution ---------------------------------------------------------------------------
@@ -205,6 +209,13 @@ class Prog:
     def run(self, stream):
         arr = self.packed()
         _lib.check(_lib.lib().frido_run(C.addressof(arr), len(self.ops), stream), "frido_run")
+
+    def run_timed(self, stream):
+        """Run with a HIP event around every op on `stream`; returns per-op device milliseconds."""
+        arr = self.packed()
+        ms = (C.c_float * len(self.ops))()
+        _lib.check(_lib.lib().frido_run_timed(C.addressof(arr), len(self.ops), stream, ms), "frido_run_timed")
+        return list(ms)
 
     def capture(self, stream):
         arr = self.packed()

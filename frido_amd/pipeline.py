@@ -1,0 +1,54 @@
+"""Batch-sharded sampling over the GPUs of one node.
+
+Every image is independent end to end (GroupNorm / LayerNorm / attention are per sample), so the
+global batch is partitioned contiguously over ranks, each rank runs the identical captured program on
+its shard with noise keyed by (seed, GLOBAL sample index), and the decoded images are joined by ONE
+RCCL all-gather over xGMI (`torch.distributed` backend "nccl" is RCCL on ROCm).  The reference's
+equivalent is N share-nothing processes writing PNGs (scripts/sample_diffusion.py:88-100,435-448).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous [lo, hi) slice of `total` samples owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_images(local, total=None, group=None):
+    """One collective joining per-rank image shards [b_r, ...] -> [sum b_r, ...] on every rank.
+    Equal shards use all_gather_into_tensor (a single RCCL all-gather); ragged shards are padded to the
+    largest shard first."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    total = total if total is not None else local.shape[0] * world
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    buf = local
+    if local.shape[0] != bmax:
+        buf = torch.zeros((bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        buf[: local.shape[0]] = local
+    out = torch.empty((world * bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    if all(hi - lo == bmax for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+@torch.no_grad()
+def sample_images(model, cond, *, S, eta=1.0, sampler="ddim", scale=1.0, uncond=None, seed=0, sample0=0, noise="philox",
+                  num_stage=None, gather=True, total=None, log_every_t=10 ** 9):
+    """cond: this rank's conditioning shard [b, nctx, cd] on the GPU.  Returns decoded images (gathered)."""
+    from .samplers import DDIMSampler, PLMSSampler
+    unet = model.model.diffusion_model
+    cls = PLMSSampler if sampler == "plms" else DDIMSampler
+    b = cond.shape[0]
+    shape = (unet.in_channels, unet.image_size, unet.image_size)
+    z, _ = cls(model).sample(S=S, batch_size=b, shape=shape, conditioning=cond, num_stage=num_stage or unet.num_stage,
+                             eta=eta, verbose=False, unconditional_guidance_scale=scale, unconditional_conditioning=uncond,
+                             noise=noise, seed=seed, sample0=sample0, log_every_t=log_every_t)
+    img = model.decode_first_stage(z)
+    return all_gather_images(img, total=total) if gather else img

@@ -1,0 +1,84 @@
+"""Plan-time tile selection for the implicit-GEMM kernel: each distinct GEMM signature is timed once per
+process on scratch buffers with every tile shape (HIP events on the launch stream) and the fastest wins.
+Disable with FRIDO_TUNE=0 (the C library's static heuristic is used instead)."""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+
+TILES = (1, 2, 3, 4, 5, 6)          # see include/frido_hip.h FridoGemm.tile
+_cache = {}
+_scratch = {}
+ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
+
+_SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
+               "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
+               "res_bs")
+
+
+def _buf(name, nbytes, device):
+    key = (name, str(device))
+    t = _scratch.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.zeros(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _scratch[key] = t
+    return t.data_ptr()
+
+
+def best_tile(st, device, stream):
+    """st: a filled FridoGemm ctypes struct (pointers are ignored: scratch buffers are substituted)."""
+    if not ENABLED:
+        return 0
+    sig = tuple(getattr(st, f) for f in _SIG_FIELDS) + (bool(st.residual), bool(st.out_f32), bool(st.out_op),
+                                                        bool(st.bias), bool(st.rowvec), bool(st.row_bias))
+    if sig in _cache:
+        return _cache[sig]
+    G = _lib.STRUCTS["FridoGemm"]
+    t = G()
+    C.memmove(C.addressof(t), C.addressof(st), C.sizeof(G))
+    ns = st.nsplit
+    if st.conv:
+        a_elems = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin
+    else:
+        a_elems = st.batch * max(st.a_bs, st.M * st.lda) if st.a_bs else st.M * st.lda
+    b_elems = st.batch * st.b_bs if st.b_bs else st.N * st.ldb
+    a_elems, b_elems = (a_elems + 7) // 8 * 8, (b_elems + 7) // 8 * 8
+    t.A, t.a_lo = _buf("A", a_elems * 2 * ns, device), a_elems
+    t.B, t.b_lo = _buf("B", b_elems * 2 * ns, device), b_elems
+    rows = st.M * st.batch
+    if st.out_f32:
+        t.out_f32 = _buf("O", max(st.of_bs * st.batch, st.M * st.ldo) * 4, device)
+    if st.out_op:
+        n = max(st.oo_bs * st.batch, st.M * st.ldoo)
+        n = (n + 7) // 8 * 8
+        t.out_op, t.oo_lo = _buf("OO", n * 2 * ns, device), n
+    if st.residual:
+        t.residual = _buf("R", max(st.res_bs * st.batch, st.M * st.ldr) * 4, device)
+    if st.bias:
+        t.bias = _buf("bias", st.N * 4, device)
+    if st.row_bias:
+        t.row_bias = _buf("rbias", st.M * 4, device)
+    if st.rowvec:
+        t.rowvec, t.rowvec_step, t.rows_per_vec, t.ldv = _buf("rv", (rows + 1) * st.N * 4, device), None, max(st.rows_per_vec, 1), st.N
+        if st.rows_per_vec >= (1 << 29):
+            t.rows_per_vec = 1 << 30
+    L = _lib.lib()
+    kind = _lib.OP_KINDS["FRIDO_OP_GEMM"]
+    reps = 3
+    best, best_t = 0, float("inf")
+    for tile in TILES:
+        if tile in (1, 2, 4) and st.M < 64:
+            continue
+        t.tile = tile
+        arr = _lib.pack_ops([(kind, t)] * (reps + 1))
+        ms = (C.c_float * (reps + 1))()
+        rc = L.frido_run_timed(C.addressof(arr), reps + 1, stream, ms)
+        if rc != 0:
+            continue
+        dt = min(list(ms)[1:])
+        if dt < best_t:
+            best, best_t = tile, dt
+    _cache[sig] = best
+    return best

@@ -69,7 +69,7 @@ typedef struct FridoGemm {
     const float* residual; int64_t res_bs; int32_t ldr;
     float* out_f32; int64_t of_bs; int32_t ldo;
     frido_bf16* out_op; int64_t oo_lo; int64_t oo_bs; int32_t ldoo;
-    int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64 */
+    int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 */
 } FridoGemm;
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two
@@ -230,6 +230,8 @@ int frido_time_emb(const FridoTimeEmb* d, frido_stream_t s);
 
 /* ---- native executor: run / capture a whole program ---- */
 int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);
+/* Same, with a HIP event recorded on `s` around every op; ms[i] = device time of op i (synchronises at the end). */
+int frido_run_timed(const FridoOp* ops, int32_t n, frido_stream_t s, float* ms);
 /* Capture `ops` into a hipGraph on stream `s` (which must be a non-default stream) and
  * instantiate it.  Returns an opaque handle in *out. */
 int frido_graph_capture(const FridoOp* ops, int32_t n, frido_stream_t s, void** out);

@@ -6,11 +6,7 @@ parity checks finish in seconds.  *_SMALL3 is the 3-scale variant of BASELINE co
 """
 import copy
 
-UNET_FULL = dict(
-    use_split_head=True, split_embed_dim_list=[3, 3], use_SPADE_norm=True, image_size=64,
-    in_channels=6, out_channels=6, model_channels=192, attention_resolutions=[8, 4, 2],
-    num_res_blocks=2, channel_mult=[1, 2, 3, 5], num_head_channels=32,
-    use_spatial_transformer=True, transformer_depth=1, context_dim=640, num_stage=2)
+from frido_amd.configs import UNET_F8F4 as UNET_FULL, VQ_F8F4 as VQ_FULL, BERT_FULL, frido_cfg  # noqa: E402,F401
 
 UNET_SMALL = dict(
     use_split_head=True, split_embed_dim_list=[3, 3], use_SPADE_norm=True, image_size=16,
@@ -23,14 +19,6 @@ UNET_SMALL3 = dict(
     in_channels=9, out_channels=9, model_channels=32, attention_resolutions=[2],
     num_res_blocks=1, channel_mult=[1, 2], num_head_channels=32,
     use_spatial_transformer=True, transformer_depth=1, context_dim=64, num_stage=3)
-
-VQ_FULL = dict(
-    embed_dim=[3, 3], n_embed=[4096, 4096],
-    edconfig=dict(multiscale=2, double_z=False, z_channels=[3, 3], resolution=256, in_channels=3,
-                  out_ch=3, ch=128, ch_mult=[1, 1, 2, 4], num_res_blocks=2, attn_resolutions=[64],
-                  dropout=0.0),
-    ddconfig=dict(double_z=False, z_channels=6, resolution=256, in_channels=3, out_ch=3, ch=128,
-                  ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[64], dropout=0.0))
 
 VQ_SMALL = dict(
     embed_dim=[3, 3], n_embed=[64, 96],
@@ -49,21 +37,3 @@ VQ_SMALL3 = dict(
                   ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16], dropout=0.0))
 
 BERT_SMALL = dict(n_embed=64, n_layer=2, vocab_size=128, max_seq_len=16, use_tokenizer=False)
-BERT_FULL = dict(n_embed=640, n_layer=32, max_seq_len=96, use_tokenizer=False)
-
-
-def frido_cfg(ucfg, vcfg, bcfg,
-              unet_target="frido.modules.diffusionmodules.pyunet.PyUNetModel",
-              vq_target="taming.models.msvqgan.VQModelInterface",
-              bert_target="frido.modules.encoders.modules.BERTEmbedder"):
-    """kwargs for FridoDiffusion(...) mirroring the reference YAML's `model.params`."""
-    return dict(
-        adopted_scale_factor=True, noise_mix_ratio=0.1, first_stage_key="image",
-        cond_stage_key="objects_bbox", linear_start=0.0015, linear_end=0.0155, num_timesteps_cond=1,
-        log_every_t=200, timesteps=1000, loss_type="l1", image_size=ucfg["image_size"],
-        channels=ucfg["in_channels"], cond_stage_trainable=True, conditioning_key="crossattn",
-        scale_by_std=True, monitor="val/loss",
-        unet_config=dict(target=unet_target, params=copy.deepcopy(ucfg)),
-        first_stage_config=dict(target=vq_target, params=dict(
-            copy.deepcopy(vcfg), lossconfig=dict(target="taming.modules.losses.DummyLoss"))),
-        cond_stage_config=dict(target=bert_target, params=copy.deepcopy(bcfg)))

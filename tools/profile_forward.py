@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Per-op device-time breakdown of one denoiser forward (and optionally the decode) using the native
+executor's per-op HIP events.  python tools/profile_forward.py [--batch 16] [--precision bf16] [--decode]"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from frido_amd import _lib, configs, synth  # noqa: E402
+from bench import build_model  # noqa: E402
+
+
+def table(prog, sp, title, top=25):
+    prog.run(sp)
+    ms = prog.run_timed(sp)
+    ms2 = prog.run_timed(sp)
+    ms = [min(a, b) for a, b in zip(ms, ms2)]
+    names = {v: k[len("FRIDO_OP_"):] for k, v in _lib.OP_KINDS.items()}
+    rows = []
+    bykind = collections.defaultdict(lambda: [0.0, 0])
+    for (kind, st), t in zip(prog.ops, ms):
+        n = names[kind]
+        desc, fl = "", 0.0
+        if n == "GEMM":
+            fl = 2.0 * st.M * st.N * st.K * st.batch
+            desc = f"M={st.M} N={st.N} K={st.K} b={st.batch} {'conv%dx%d s%d u%d d%d' % (st.kh, st.kw, st.stride, st.up_shift, st.dn_shift) if st.conv else 'dense'}"
+            n = "GEMM-conv" if st.conv else "GEMM"
+        rows.append((t, n, desc, fl))
+        bykind[n][0] += t
+        bykind[n][1] += 1
+    tot = sum(ms)
+    print(f"== {title}: {len(ms)} ops, {tot:.3f} ms (sum of per-op event intervals)")
+    for k, (t, c) in sorted(bykind.items(), key=lambda kv: -kv[1][0]):
+        print(f"  {k:12s} {c:4d} launches {t:8.3f} ms {100 * t / tot:5.1f}%")
+    agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for t, n, desc, fl in rows:
+        a = agg[(n, desc)]
+        a[0] += t; a[1] += 1; a[2] += fl
+    print("  top shapes:")
+    for (n, desc), (t, c, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+        tf = fl / (t * 1e-3) / 1e12 if fl else 0
+        print(f"   {t:8.3f} ms x{c:3d} {n:10s} {desc:60s} {tf:7.1f} TF/s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--decode", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    model = build_model(a.precision, dev)
+    from frido_amd.samplers import DDIMSampler
+    ctx = torch.from_numpy(synth.seeded_normal("bench:ctx", (a.batch, 26, 640))).to(dev)
+    z, _ = DDIMSampler(model).sample(S=2, batch_size=a.batch, shape=(6, 64, 64), conditioning=ctx, num_stage=2, eta=1.0,
+                                     verbose=False, noise="philox")
+    rt = model.model.diffusion_model.runtime()
+    eng = next(iter(rt._sampler_engines.values()))
+    sp = torch.cuda.current_stream().cuda_stream
+    eng.step.zero_()   # the step counter indexes the timestep table: rewind it after the sampling run
+    table(eng.stages[0].step, sp, "stage-0 forward")
+    table(eng.stages[1].step, sp, "stage-1 forward")
+    table(eng.stages[1].pre, sp, "stage-1 pre (hoisted)")
+    if a.decode:
+        model.decode_first_stage(z)
+        drt = model.first_stage_model.runtime()
+        plan = next(iter(drt.plans.values()))[1]
+        table(plan.prog, sp, "VQGAN decode")
+
+
+if __name__ == "__main__":
+    main()
