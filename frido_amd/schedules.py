@@ -12,13 +12,27 @@ import numpy as np
 COEF_ROW = 12   # must match csrc/misc.hip: a_t, a_prev, sigma, sqrt(1-a_t), ab0..ab3, den, pad
 
 
+def _linspace(start, end, steps):
+    """torch.linspace's float64 evaluation (what the reference's schedule is built with): symmetric — first half
+    fma(step, i, start), second half fma(-step, steps-1-i, end) — with FUSED multiply-adds, emulated here through
+    80-bit long doubles (the product step*i is exact in 64 mantissa bits for i < 2^11).  np.linspace differs in
+    the last bit for ~15 % of the entries."""
+    L = np.longdouble
+    start, end = np.float64(start), np.float64(end)
+    step = (end - start) / np.float64(steps - 1)
+    i = np.arange(steps)
+    lo = (L(step) * i.astype(L) + L(start)).astype(np.float64)
+    hi = (L(end) - L(step) * (steps - 1 - i).astype(L)).astype(np.float64)
+    return np.where(i < steps // 2, lo, hi)
+
+
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     if schedule == "linear":
-        return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+        return _linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep) ** 2
     if schedule == "sqrt_linear":
-        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
+        return _linspace(linear_start, linear_end, n_timestep)
     if schedule == "sqrt":
-        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64) ** 0.5
+        return _linspace(linear_start, linear_end, n_timestep) ** 0.5
     if schedule == "cosine":
         ts = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
         al = np.cos(ts / (1 + cosine_s) * np.pi / 2) ** 2
@@ -51,13 +65,15 @@ def make_ddim_timesteps(method, num_ddim, num_ddpm):
 
 
 def make_ddim_sampling_parameters(alphacums32, ddim_timesteps, eta):
-    """alphacums32: float32 alphas_cumprod.  Returns (sigmas f64, alphas f32, alphas_prev f64) like the
-    reference's tensor/ndarray mix: (1 - alphas) is formed in float32, everything else in float64."""
+    """alphacums32: float32 alphas_cumprod.  Returns (sigmas f64, alphas f32, alphas_prev f64) with the reference's
+    exact float mix (util.py:63-74 evaluated on a float32 torch tensor and a float64 ndarray, as ddim.py:43-46 does):
+    `ndarray / tensor` dispatches to Tensor.__rtruediv__ = reciprocal(tensor) * ndarray, so 1/(1 - alphas) is formed
+    in FLOAT32 and only then widened; everything else is float64."""
     ac = np.asarray(alphacums32, dtype=np.float32)
     alphas = ac[ddim_timesteps]
     alphas_prev = np.asarray([ac[0]] + ac[ddim_timesteps[:-1]].tolist(), dtype=np.float64)
-    one_minus_a = (np.float32(1.0) - alphas).astype(np.float64)
-    sigmas = eta * np.sqrt((1 - alphas_prev) / one_minus_a * (1 - alphas.astype(np.float64) / alphas_prev))
+    recip = (np.float32(1.0) / (np.float32(1.0) - alphas)).astype(np.float32).astype(np.float64)
+    sigmas = eta * np.sqrt(recip * (1 - alphas_prev) * (1 - alphas.astype(np.float64) / alphas_prev))
     return sigmas, alphas, alphas_prev
 
 

@@ -1,0 +1,51 @@
+"""N > 1 path on CPU: two gloo ranks shard a global batch contiguously and join their "decoded images" with the one
+all-gather frido_amd.pipeline uses on RCCL (the same torch.distributed call; only the backend differs)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from frido_amd.pipeline import shard_range
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_contiguously():
+    for total in (1, 7, 16, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from frido_amd.pipeline import shard_range, all_gather_images
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+for total in (8, 7):
+    lo, hi = shard_range(total, rank, world)
+    # a rank's "decoded images" depend only on GLOBAL sample indices, like the Philox-keyed sampler
+    local = torch.stack([torch.full((3, 4, 4), float(i)) for i in range(lo, hi)])
+    full = all_gather_images(local, total=total)
+    assert full.shape == (total, 3, 4, 4), full.shape
+    assert torch.equal(full[:, 0, 0, 0], torch.arange(total, dtype=torch.float32)), full[:, 0, 0, 0]
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_all_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % REPO)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

@@ -1,0 +1,114 @@
+"""CPU-side checks of the host logic: schedule tables vs the reference goldens, the C-ABI library (loads, exports
+every declared symbol, struct sizes agree with the header), the reference's class/config surface, and the absence
+of any CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+from golden_cfg import UNET_SMALL, VQ_SMALL, BERT_SMALL, UNET_FULL, frido_cfg
+from frido_amd import _lib, schedules
+
+
+def test_schedule_tables_match_reference_bitwise():
+    g = golden("schedules")
+    betas = schedules.make_beta_schedule("linear", 1000, linear_start=0.0015, linear_end=0.0155)
+    assert np.array_equal(betas, g["betas64"])
+    tabs = schedules.ddpm_tables(betas)
+    assert np.array_equal(tabs["betas"], g["betas"]) and np.array_equal(tabs["alphas_cumprod"], g["alphas_cumprod"])
+    for S in (4, 50, 100, 200, 250):
+        ts = schedules.make_ddim_timesteps("uniform", S, 1000)
+        assert np.array_equal(ts, g[f"ts_{S}"])
+        for eta in (0.0, 1.0):
+            sig, a, ap = schedules.make_ddim_sampling_parameters(tabs["alphas_cumprod"], ts, eta)
+            tag = f"{S}_{int(eta)}"
+            assert np.array_equal(a, g[f"alphas_{tag}"]) and np.array_equal(ap, g[f"alphas_prev_{tag}"])
+            assert np.array_equal(sig, g[f"sigmas_{tag}"])
+            tab, t_loop = schedules.sampler_coef_table(tabs["alphas_cumprod"], S, eta)
+            n = ts.shape[0]
+            assert tab.shape == (n, schedules.COEF_ROW) and np.array_equal(t_loop, ts[::-1])
+            assert np.array_equal(tab[:, 0], a[::-1].astype(np.float32))
+            assert np.array_equal(tab[:, 1], ap[::-1].astype(np.float32))
+            assert np.array_equal(tab[:, 3], g[f"sqrt1m_{tag}"][::-1].astype(np.float32))
+    tab, _ = schedules.sampler_coef_table(tabs["alphas_cumprod"], 50, 0.0, plms=True)
+    assert tab[0, 4:9].tolist() == [1, 1, 0, 0, 2] and tab[1, 4:9].tolist() == [3, -1, 0, 0, 2]
+    assert tab[2, 4:9].tolist() == [23, -16, 5, 0, 12] and tab[7, 4:9].tolist() == [55, -59, 37, -9, 24]
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), f"libfrido_hip.so lacks {name} (declared in include/frido_hip.h)"
+    assert L.frido_abi_version() == 1
+    assert L.frido_sizeof_op() == C.sizeof(_lib.FridoOp)
+    for kname, sname in _lib.KIND_STRUCT.items():
+        assert L.frido_sizeof_desc(_lib.OP_KINDS[kname]) == C.sizeof(_lib.STRUCTS[sname]), sname
+
+
+def test_bad_descriptors_are_rejected_without_touching_a_device():
+    L = _lib.lib()
+    kind, st = _lib.make_op("FRIDO_OP_GEMM", M=16, N=16, K=20, batch=1, nsplit=1)     # K not a multiple of 32
+    assert L.frido_gemm(C.addressof(st), None) == -1
+    assert b"multiple of 32" in L.frido_last_error()
+    kind, st = _lib.make_op("FRIDO_OP_SOFTMAX", rows=4, N=5000, Npad=5024)
+    assert L.frido_softmax(C.addressof(st), None) == -1
+
+
+def test_reference_targets_resolve_and_state_dict_layout():
+    from frido_amd.models import instantiate_from_config
+    import frido.models.diffusion.frido as F
+    import ldm.models.diffusion.msldm as L
+    import ldm.modules.diffusionmodules.openaimodel as O
+    import frido.modules.diffusionmodules.pyunet as P
+    assert L.MSLatentDiffusion is F.FridoDiffusion and O.UNetModel is P.PyUNetModel
+    cfg = frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    cfg["cond_stage_config"] = "__is_unconditional__"
+    cfg["conditioning_key"] = "crossattn"
+    m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    keys = set(m.state_dict().keys())
+    g = golden("unet_small")
+    assert {"model.diffusion_model." + k for k in g["keys"]} <= keys
+    assert {"first_stage_model." + k for k in golden("vq_small")["keys"]} <= keys
+    assert {"scale_factor", "betas", "alphas_cumprod", "model_ema.decay", "model_ema.num_updates"} <= keys
+    ema = [k for k in keys if k.startswith("model_ema.diffusion_model")]
+    assert len(ema) == len(g["keys"]) and all("." not in k[len("model_ema."):] for k in ema)     # ema.py:16-20 mangling
+    assert m.scale_factor.shape == (2,) and m.num_timesteps == 1000
+    assert m.model.diffusion_model.num_stage == 2 and m.embed_dim_list == [3, 3] and m.use_split_head
+    with pytest.raises(KeyError):
+        instantiate_from_config({"params": {}})
+
+
+def test_no_cpu_fallback_anywhere():
+    from frido_amd._lib import FridoHipError
+    from frido_amd.models import PyUNetModel, VQModelInterface
+    from frido_amd.samplers import DDIMSampler
+    u = PyUNetModel(**UNET_SMALL)
+    with pytest.raises(FridoHipError):
+        u(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 5, 64), stage=0)
+    v = VQModelInterface(**VQ_SMALL, lossconfig=dict(target="taming.modules.losses.DummyLoss"))
+    with pytest.raises(FridoHipError):
+        v.decode(torch.zeros(1, 6, 16, 16))
+
+    class M:
+        num_timesteps = 1000
+    with pytest.raises(FridoHipError):
+        DDIMSampler(M()).sample(S=4, batch_size=1, shape=(6, 16, 16), conditioning=torch.zeros(1, 5, 64), verbose=False)
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "frido_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_full_width_holder_has_reference_parameter_count():
+    from helpers import unet_holder
+    assert sum(p.numel() for p in unet_holder(UNET_FULL).parameters()) == int(golden("unet_full")["nparam"]) == 511669446   # the reference module (SURVEY App. A rounds to 511.67 M)
