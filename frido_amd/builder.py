@@ -136,7 +136,7 @@ class Builder:
 
     def gn_stats(self, x1, x2, B, HW):
         C = x1.C + (x2.C if x2 is not None else 0)
-        S = max(1, min(64, HW // 64, max(1, 1024 // B)))
+        S = max(1, min(64, HW // 4, max(1, 1024 // B)))     # ~1024 workgroups, at least 4 pixels each
         part = self.pool.alloc(B * S * 32 * 2 * 8)
         self.prog.emit("FRIDO_OP_GN_STATS", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
                        C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr())

@@ -120,10 +120,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
         b_off[j] = (int64_t)n * d.ldb + lq * 8;
     }
 
-    const int nk = d.K >> 5;
+    // k-tile range of this workgroup (split-K: gridDim.z slices)
+    const int nk_all = d.K >> 5;
+    const int kz = blockIdx.z;
+    const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = kz * per;
+    const int nk = max(0, min(nk_all, kt0 + per) - kt0);
+    const int cin = d.Cin, kw = d.kw, ws = d.Ws;
     int kc = 0, ky = 0, kx = 0, tap = 0;   // conv k-walk (uniform): channel offset inside the tap, tap coordinates
     int64_t tap_off = 0;                   // ((ky * Ws + kx) * Cin + kc): offset of the current k-tile from tap (0,0)
-    const int cin = d.Cin, kw = d.kw, ws = d.Ws;
+    if (CONV && kt0) {
+        const int cpt = cin >> 5;
+        tap = kt0 / cpt;
+        kc = (kt0 - tap * cpt) << 5;
+        ky = tap / kw;
+        kx = tap - ky * kw;
+        tap_off = ((int64_t)ky * ws + kx) * cin + kc;
+    }
     // keep the zero page's address in SGPRs (otherwise hipcc re-loads it from the GOT inside the k-loop)
     unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
     asm volatile("" : "+s"(zero_addr));
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     // ---- prologue: fill D-1 stages ----
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
-        if (s < nk) issue(s, s);
+        if (s < nk) issue(kt0 + s, s);
 
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
         if (kt + D - 1 < nk) {
             int nb_ = buf + D - 1;
             nb_ = nb_ >= D ? nb_ - D : nb_;
-            issue(kt + D - 1, nb_);
+            issue(kt0 + kt + D - 1, nb_);
         }
         const unsigned sa = a_frag + buf * STAGE, sbb = b_frag + buf * STAGE;
         bf16x8 fa[NS][TM];
@@ -241,6 +254,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
 
     // ---- epilogue: lane holds D[row = (lane>>4)*4 + e][col = lane & 15] of each 16x16 tile ----
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    if (gridDim.z > 1) {      // split-K: raw partial sums; splitk_reduce_kernel applies the epilogue
+        float* wsp = d.ws + (int64_t)kz * d.M * d.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + col_l;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 16 + row_l + e;
+                    if (m < d.M) wsp[(int64_t)m * d.N + n] = acc[i][j][e];
+                }
+        }
+        return;
+    }
     int vstep = 0;
     if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
 #pragma unroll
@@ -267,6 +296,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
+    const int64_t total = (int64_t)d.M * d.N;
+    int vstep = 0;
+    if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / d.N), n = (int)(i - (int64_t)m * d.N);
+        float a = 0.f;
+        for (int z = 0; z < d.splitk; ++z) a += d.ws[(int64_t)z * total + i];
+        float v = a * d.alpha + (d.bias ? d.bias[n] : 0.f);
+        if (d.row_bias) v += d.row_bias[m];
+        if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
+        if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
+        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
+        if (d.out_f32) d.out_f32[(int64_t)m * d.ldo + n] = v;
+        if (d.out_op) store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
+    }
+}
+
 template <int BM, int BN, int NS, bool CONV>
 int set_attr() {
     constexpr int smem = Geo<BM, BN, NS>::SMEM;
@@ -282,7 +330,13 @@ template <int BM, int BN, int NS, bool CONV>
 int launch(const FridoGemm& d, hipStream_t s) {
     constexpr int smem = Geo<BM, BN, NS>::SMEM;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV>), dim3(tiles, d.batch), dim3(256), smem, s, d);
+    const int sk = d.splitk > 1 ? d.splitk : 1;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV>), dim3(tiles, d.batch, sk), dim3(256), smem, s, d);
+    if (sk > 1) {
+        const int64_t total = (int64_t)d.M * d.N;
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
+    }
     return frido_check_launch("igemm");
 }
 
@@ -340,6 +394,10 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
         FRIDO_REQUIRE((d.lda & 7) == 0 && (d.a_bs & 7) == 0, "A rows must be 16-byte aligned");
     }
     if (d.rowvec) FRIDO_REQUIRE(d.rows_per_vec > 0, "rows_per_vec");
+    if (d.splitk > 1) {
+        FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
+        FRIDO_REQUIRE(d.splitk <= (d.K >> 5), "more K slices than k-tiles");
+    }
     const int tile = d.tile ? d.tile : pick_tile(d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d.nsplit == 1) return d.conv ? dispatch_tile<1, true>(d, tile, s) : dispatch_tile<1, false>(d, tile, s);

@@ -63,22 +63,33 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
 // GroupNorm apply: grid (blocks_per_image, B); prologue turns the partials into {mean, rstd}.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
     __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_part[8][64][2];
     const int C = d.C1 + d.C2, C4 = C >> 2;
     const int t = threadIdx.x, b = blockIdx.y;
     const int cpg = C / d.groups;
-    if (t < d.groups) {
+    {   // combine the per-split partials: 8 lanes per group in parallel, then a fixed-order sum of the 8
+        const int g = t & 31, l8 = t >> 5;
         double s = 0.0, q = 0.0;
-        for (int sp = 0; sp < d.nsplit_px; ++sp) {
-            const double* p = d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + t) * 2;
-            s += p[0];
-            q += p[1];
+        if (g < d.groups) {
+            for (int sp = l8; sp < d.nsplit_px; sp += 8) {
+                const double2 p = *reinterpret_cast<const double2*>(d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + g) * 2);
+                s += p.x;
+                q += p.y;
+            }
+            s_part[l8][g][0] = s;
+            s_part[l8][g][1] = q;
         }
-        const double n = (double)d.HW * cpg;
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        s_mean[t] = (float)mean;
-        s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+        __syncthreads();
+        if (t < d.groups) {
+            s = 0.0; q = 0.0;
+            for (int l = 0; l < 8; ++l) { s += s_part[l][t][0]; q += s_part[l][t][1]; }
+            const double n = (double)d.HW * cpg;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mean[t] = (float)mean;
+            s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+        }
     }
     __syncthreads();
     const int64_t total = (int64_t)d.HW * C4;
@@ -234,7 +245,7 @@ extern "C" int frido_gn_stats(const FridoGnStats* d, frido_stream_t s) {
 extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->x1 && d->partials && d->weight && d->bias, "null pointer");
     const int C = d->C1 + d->C2;
-    FRIDO_REQUIRE(d->groups > 0 && d->groups <= 64 && C % d->groups == 0, "channels not divisible by groups");
+    FRIDO_REQUIRE(d->groups > 0 && d->groups <= 32 && C % d->groups == 0, "channels not divisible by groups (<= 32 groups)");
     FRIDO_REQUIRE((d->C1 & 3) == 0 && (d->C2 & 3) == 0, "channel counts must be multiples of 4");
     FRIDO_REQUIRE(d->out_op || d->out_f32, "no output");
     FRIDO_REQUIRE((d->gamma == nullptr) == (d->beta == nullptr), "gamma/beta must come together");

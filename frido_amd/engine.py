@@ -197,7 +197,9 @@ class Prog:
         if not tile and self.device.type == "cuda":
             from . import tune
             st = self.ops[-1][1]
-            st.tile = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
+            st.tile, st.splitk = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
+            if st.splitk > 1:
+                st.ws = tune.workspace(self.device, st.splitk * M * N * 4)
         self.flops += 2 * M * N * K * batch * (3 if self.nsplit == 2 else 1)
 
     # ---- execution ---------------------------------------------------------------------------

@@ -27,10 +27,27 @@ def _buf(name, nbytes, device):
     return t.data_ptr()
 
 
+_ws = {}
+
+
+def workspace(device, nbytes):
+    """Process-wide split-K workspace (ops of all programs run in stream order, so one buffer is enough)."""
+    key = str(device)
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        old = t
+        t = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=device)
+        _ws[key] = t
+        if old is not None:
+            _ws.setdefault(key + ":old", []).append(old)      # descriptors emitted earlier still point at it
+    return t.data_ptr()
+
+
 def best_tile(st, device, stream):
-    """st: a filled FridoGemm ctypes struct (pointers are ignored: scratch buffers are substituted)."""
+    """st: a filled FridoGemm ctypes struct (pointers are ignored: scratch buffers are substituted).
+    Returns (tile, splitk)."""
     if not ENABLED:
-        return 0
+        return 0, 1
     sig = tuple(getattr(st, f) for f in _SIG_FIELDS) + (bool(st.residual), bool(st.out_f32), bool(st.out_op),
                                                         bool(st.bias), bool(st.rowvec), bool(st.row_bias))
     if sig in _cache:
@@ -67,18 +84,26 @@ def best_tile(st, device, stream):
     L = _lib.lib()
     kind = _lib.OP_KINDS["FRIDO_OP_GEMM"]
     reps = 3
-    best, best_t = 0, float("inf")
-    for tile in TILES:
-        if tile in (1, 2, 4) and st.M < 64:
-            continue
-        t.tile = tile
-        arr = _lib.pack_ops([(kind, t)] * (reps + 1))
-        ms = (C.c_float * (reps + 1))()
-        rc = L.frido_run_timed(C.addressof(arr), reps + 1, stream, ms)
-        if rc != 0:
-            continue
-        dt = min(list(ms)[1:])
-        if dt < best_t:
-            best, best_t = tile, dt
+    best, best_t = (0, 1), float("inf")
+    nk = st.K // 32
+    small = st.batch == 1 and st.M * st.N <= (1 << 23)       # split-K only pays for small outputs with a long K
+    splits = [1] + [k for k in (2, 4, 8) if small and nk >= 4 * k]
+    for sk in splits:
+        t.splitk = sk
+        t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None
+        for tile in TILES:
+            if tile in (1, 2, 4) and st.M < 64:
+                continue
+            if sk > 1 and tile in (1, 2):
+                continue
+            t.tile = tile
+            arr = _lib.pack_ops([(kind, t)] * (reps + 1))
+            ms = (C.c_float * (reps + 1))()
+            rc = L.frido_run_timed(C.addressof(arr), reps + 1, stream, ms)
+            if rc != 0:
+                continue
+            dt = min(list(ms)[1:])
+            if dt < best_t:
+                best, best_t = (tile, sk), dt
     _cache[sig] = best
     return best

@@ -69,6 +69,9 @@ typedef struct FridoGemm {
     const float* residual; int64_t res_bs; int32_t ldr;
     float* out_f32; int64_t of_bs; int32_t ldo;
     frido_bf16* out_op; int64_t oo_lo; int64_t oo_bs; int32_t ldoo;
+    int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to `ws` [splitk][M][N] f32 and a
+                                   second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
+    float* ws;
     int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 */
 } FridoGemm;
 

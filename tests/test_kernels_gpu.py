@@ -77,6 +77,43 @@ def test_gemm_batched_operand_out_and_rowbias(nsplit):
     assert _relerr(o.to_f32().cpu().view(B, M, N), ref) < (1e-5 if nsplit == 2 else 2e-2)
 
 
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("conv", [False, True])
+@pytest.mark.parametrize("splitk,tile", [(2, 3), (4, 6), (7, 4)])
+def test_gemm_split_k_is_deterministic_and_correct(nsplit, conv, splitk, tile):
+    from frido_amd import tune
+    from frido_amd.builder import ACT_SILU
+    if conv:
+        B, H, W, Cin, Cout = 2, 8, 8, 96, 70
+        x, w, bias = _t("kx", B, Cin, H, W), _t("kw", Cout, Cin, 3, 3) / np.sqrt(9 * Cin), _t("kb", Cout)
+        res = _t("kr", B * H * W, Cout)
+        ref = F.silu(F.conv2d(x, w, bias, padding=1)).permute(0, 2, 3, 1).reshape(-1, Cout) + res
+        b = _builder(nsplit, {"c.weight": w.cuda(), "c.bias": bias.cuda()})
+        xd = x.cuda()
+        a = b.pack(xd.data_ptr(), B, H * W, Cin, 0, Cin, nchw=True)
+        r = b.f32(B * H * W, Cout)
+        r.view().copy_(res.cuda())
+        out = b.conv(a, B, H, W, "c", act=ACT_SILU, residual=r)
+    else:
+        M, N, K = 200, 150, 32 * 23
+        a_, w, bias, res = _t("ka", M, K), _t("kw2", N, K) / np.sqrt(K), _t("kb2", N), _t("kr2", M, N)
+        ref = F.silu(a_ @ w.t() + bias) + res
+        b = _builder(nsplit, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+        ad = a_.cuda()
+        a = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+        r = b.f32(M, N)
+        r.view().copy_(res.cuda())
+        out = b.linear(a, "w", act=ACT_SILU, residual=r)
+    st = b.prog.ops[-1][1]
+    st.tile, st.splitk = tile, splitk
+    st.ws = tune.workspace(_dev(), splitk * st.M * st.N * 4)
+    _run(b)
+    first = out.view().clone()
+    assert _relerr(first.cpu(), ref) < _tol(nsplit)
+    _run(b)
+    assert torch.equal(first, out.view())        # fixed-order reduction: bit-reproducible
+
+
 CONV_CASES = [
     # Cin, Cout, H, W, k, stride, pad, up, dn, asym
     (32, 64, 16, 16, 3, 1, 1, 0, 0, False),
