@@ -74,6 +74,29 @@ class Builder:
             self._wcache[key] = pack_matrix(w, self.nsplit)
         return self._wcache[key]
 
+    def geglu_weight(self, wname):
+        """GEGLU projection [2H][K] with rows regrouped in 16-row blocks [a_0..15 | gate_0..15 | a_16..31 | ...] so that
+        a value and its gate land in the same lane of adjacent MFMA column tiles; returns (operand, bias ptr, H)."""
+        key = ("geglu", wname)
+        if key not in self._wcache:
+            w = self.w[wname + ".weight"].float()
+            bvec = self.w[wname + ".bias"].float()
+            H = w.shape[0] // 2
+            assert H % 16 == 0
+            idx = torch.arange(H, device=w.device).view(-1, 16)
+            perm = torch.stack([idx, idx + H], dim=1).reshape(-1)
+            bp = bvec[perm].contiguous()
+            self._wcache[key] = (pack_matrix(w[perm], self.nsplit), bp, H)
+        return self._wcache[key]
+
+    def linear_geglu(self, a, wname):
+        """operand [M][H] = a_proj * gelu(gate_proj) of the GEGLU projection `wname` (attention.py:37-44) in ONE GEMM."""
+        wop, bp, H = self.geglu_weight(wname)
+        M = a.rows * getattr(a, "batch", 1)
+        o = self.op(M, H)
+        self.prog.gemm(M, 2 * H, wop.K, a, wop, bias=bp.data_ptr(), out_op=o.ptr, ldoo=H, oo_lo=o.lo, geglu=1)
+        return o
+
     def bias(self, name):
         return self.dev_f32(name).data_ptr() if name in self.w else None
 

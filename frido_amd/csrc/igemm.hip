@@ -270,6 +270,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
         }
         return;
     }
+    if (d.geglu) {            // fused GEGLU: tile column block j holds `a`, block j+1 the matching gate
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + col_l;
+            if (n + 16 >= d.N) continue;
+            const float ba = d.bias ? d.bias[n] : 0.f, bg = d.bias ? d.bias[n + 16] : 0.f;
+            const int oc = (n >> 5) * 16 + col_l;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 16 + row_l + e;
+                    if (m >= d.M) continue;
+                    const float a = acc[i][j][e] * d.alpha + ba, g = acc[i][j + 1][e] * d.alpha + bg;
+                    const float v = a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+                    store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + oc, v);
+                }
+        }
+        return;
+    }
     int vstep = 0;
     if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
 #pragma unroll
@@ -394,6 +414,10 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
         FRIDO_REQUIRE((d.lda & 7) == 0 && (d.a_bs & 7) == 0, "A rows must be 16-byte aligned");
     }
     if (d.rowvec) FRIDO_REQUIRE(d.rows_per_vec > 0, "rows_per_vec");
+    if (d.geglu) {
+        FRIDO_REQUIRE((d.N & 31) == 0 && d.out_op && !d.out_f32 && d.batch == 1 && d.splitk <= 1 && !d.residual && !d.rowvec,
+                      "geglu epilogue: N % 32 == 0, operand output only, no split-K / residual / rowvec");
+    }
     if (d.splitk > 1) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
         FRIDO_REQUIRE(d.splitk <= (d.K >> 5), "more K slices than k-tiles");

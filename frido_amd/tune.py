@@ -14,7 +14,7 @@ _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
 
 _SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
-               "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
+               "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
                "res_bs")
 
 
@@ -86,7 +86,7 @@ def best_tile(st, device, stream):
     reps = 3
     best, best_t = (0, 1), float("inf")
     nk = st.K // 32
-    small = st.batch == 1 and st.M * st.N <= (1 << 23)       # split-K only pays for small outputs with a long K
+    small = st.batch == 1 and st.M * st.N <= (1 << 23) and not st.geglu       # split-K only pays for small outputs with a long K
     splits = [1] + [k for k in (2, 4, 8) if small and nk >= 4 * k]
     for sk in splits:
         t.splitk = sk

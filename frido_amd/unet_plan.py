@@ -238,10 +238,8 @@ class UNetStagePlan:
         h2.free()
         # --- GEGLU feed-forward (attention.py:37-64)
         n3 = b.layernorm(h3, t + ".norm3")
-        g = b.linear(n3, t + ".ff.net.0.proj")
+        gg = b.linear_geglu(n3, t + ".ff.net.0.proj")
         n3.free()
-        gg = b.geglu(g, 4 * C)
-        g.free()
         h4 = b.linear(gg, t + ".ff.net.2", residual=h3, out="op")
         gg.free()
         h3.free()

@@ -66,6 +66,8 @@ typedef struct FridoGemm {
     const float* rowvec; int32_t rows_per_vec; int32_t ldv;   /* row index m / rows_per_vec + *rowvec_step */
     const int32_t* rowvec_step;
     int32_t act;
+    int32_t geglu;              /* 1: weight rows are interleaved in 16-row blocks [a | gate]; the epilogue writes
+                                   (a) * gelu_erf(gate) as an operand [M][N/2] (attention.py:42-44), no f32 output */
     const float* residual; int64_t res_bs; int32_t ldr;
     float* out_f32; int64_t of_bs; int32_t ldo;
     frido_bf16* out_op; int64_t oo_lo; int64_t oo_bs; int32_t ldoo;

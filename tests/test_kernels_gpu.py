@@ -230,6 +230,19 @@ def test_geglu():
     assert _relerr(o.to_f32().cpu(), a * F.gelu(g)) < 2e-5
 
 
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("M,C", [(300, 64), (1024, 384), (64, 960)])
+def test_fused_geglu_projection(nsplit, M, C):
+    x, w, bias = _t("fx", M, C), _t("fw", 8 * C, C) / np.sqrt(C), _t("fb", 8 * C)
+    b = _builder(nsplit, {"p.weight": w.cuda(), "p.bias": bias.cuda()})
+    xd = x.cuda()
+    a = b.pack(xd.data_ptr(), 1, M, C, 0, C)
+    o = b.linear_geglu(a, "p")
+    _run(b)
+    h, g = (x @ w.t() + bias).chunk(2, dim=-1)
+    assert _relerr(o.to_f32().cpu(), h * F.gelu(g)) < _tol(nsplit)
+
+
 def test_pack_relayout_roundtrip():
     B, C, H, W = 2, 6, 8, 8
     x = _t("px", B, C, H, W)
