@@ -5,7 +5,7 @@ descriptors, owning the packed-weight cache and the activation pool.  The U-Net 
 import torch
 
 from . import _lib
-from .engine import (Operand, POperand, F32, Pool, Prog, pack_matrix, pack_conv_weight, rup)
+from .engine import (Operand, POperand, F32, Alias, Pool, Prog, pack_matrix, pack_conv_weight, rup)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 
@@ -19,6 +19,9 @@ class Builder:
         self.prog = Prog(self.device, nsplit)
         self._wcache = {}
         self._persist = []              # tensors that must outlive the builder's programs
+        # bf16 mode keeps the residual stream itself in bf16 (it then doubles as the MFMA operand: no pack passes);
+        # bf16x3 (fp32-class parity mode) keeps an f32 stream
+        self.stream_bf16 = nsplit == 1
 
     # ---- programs ------------------------------------------------------------------------------
     def new_prog(self):
@@ -28,7 +31,12 @@ class Builder:
 
     # ---- allocation -----------------------------------------------------------------------------
     def f32(self, rows, C):
-        return F32(self.pool, rows, C)
+        """Residual-stream activation (bf16 in bf16 mode)."""
+        return F32(self.pool, rows, C, bf16=self.stream_bf16)
+
+    def f32_strict(self, rows, C):
+        """Always-f32 scratch (attention scores, tiny heads)."""
+        return F32(self.pool, rows, C, bf16=False)
 
     def op(self, rows, K, batch=1):
         return POperand(self.pool, rows, K, self.nsplit, batch=batch)
@@ -138,6 +146,9 @@ class Builder:
         res = None
         if out == "f32":
             res = self.f32(M, N)
+            kw.update(out_f32=res.ptr, ldo=N, out_bf16=res.bf16)
+        elif out == "f32_strict":
+            res = self.f32_strict(M, N)
             kw.update(out_f32=res.ptr, ldo=N)
         elif out == "op":
             res = self.op(M, rup(N, 32))
@@ -146,11 +157,11 @@ class Builder:
         elif isinstance(out, tuple):        # ("f32"|"op", existing buffer)
             kind, res = out
             if kind == "f32":
-                kw.update(out_f32=res.ptr, ldo=res.C)
+                kw.update(out_f32=res.ptr, ldo=res.C, out_bf16=getattr(res, "bf16", False))
             else:
                 kw.update(out_op=res.ptr, ldoo=res.K, oo_lo=res.lo)
         if residual is not None:
-            kw.update(residual=residual.ptr, ldr=residual.C)
+            kw.update(residual=residual.ptr, ldr=residual.C, res_bf16=getattr(residual, "bf16", False))
         if rowvec is not None:
             kw.update(rowvec=rowvec["ptr"], rows_per_vec=rowvec["rows_per_vec"], ldv=rowvec["ld"],
                       rowvec_step=rowvec.get("step"))
@@ -158,11 +169,13 @@ class Builder:
         return res
 
     def gn_stats(self, x1, x2, B, HW):
-        C = x1.C + (x2.C if x2 is not None else 0)
         S = max(1, min(64, HW // 4, max(1, 1024 // B)))     # ~1024 workgroups, at least 4 pixels each
         part = self.pool.alloc(B * S * 32 * 2 * 8)
+        xb = getattr(x1, "bf16", False)
+        assert x2 is None or getattr(x2, "bf16", False) == xb
         self.prog.emit("FRIDO_OP_GN_STATS", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
-                       C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr())
+                       C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr(),
+                       x_bf16=int(xb))
         return part, S
 
     def groupnorm(self, x1, x2, B, HW, wname, eps, *, gamma=None, beta=None, act=ACT_NONE, want_raw=False,
@@ -171,16 +184,21 @@ class Builder:
         C = x1.C + (x2.C if x2 is not None else 0)
         part, S = self.gn_stats(x1, x2, B, HW)
         a = self.op(B * HW, C)
-        raw = self.op(B * HW, C) if want_raw else None
-        of = self.f32(B * HW, C) if out_f32 else None
+        xb = getattr(x1, "bf16", False)
+        alias_raw = want_raw and xb and x2 is None          # a bf16 activation already IS its own operand
+        raw = None if (not want_raw or alias_raw) else self.op(B * HW, C)
+        of = self.f32_strict(B * HW, C) if out_f32 else None
         self.prog.emit("FRIDO_OP_GN_APPLY", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
                        C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr(),
                        eps=eps, weight=self.bias(wname + ".weight"), bias=self.bias(wname + ".bias"),
                        gamma=gamma.ptr if gamma is not None else None, beta=beta.ptr if beta is not None else None,
                        act=act, nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo,
                        raw_op=raw.ptr if raw is not None else None, raw_lo=raw.lo if raw is not None else 0,
-                       out_f32=of.ptr if of is not None else None)
+                       out_f32=of.ptr if of is not None else None, x_bf16=int(xb),
+                       gb_bf16=int(getattr(gamma, "bf16", False)) if gamma is not None else 0)
         self.pool.release(part)
+        if alias_raw:
+            raw = Alias(x1)
         if out_f32:
             return a, raw, of
         return a, raw
@@ -188,7 +206,8 @@ class Builder:
     def layernorm(self, x, wname, eps=1e-5):
         a = self.op(x.rows, x.C)
         self.prog.emit("FRIDO_OP_LAYERNORM", x=x.ptr, rows=x.rows, C=x.C, eps=eps, weight=self.bias(wname + ".weight"),
-                       bias=self.bias(wname + ".bias"), nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo)
+                       bias=self.bias(wname + ".bias"), nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo,
+                       x_bf16=int(getattr(x, "bf16", False)))
         return a
 
     def softmax(self, s, rows, N, ld, Npad):
@@ -210,7 +229,9 @@ class Builder:
         return o
 
     def to_operand(self, x):
-        """f32 [rows][C] -> operand (C % 32 == 0)."""
+        """activation [rows][C] -> operand (C % 32 == 0); a bf16 activation is its own operand."""
+        if getattr(x, "bf16", False):
+            return Alias(x)
         return self.pack(x.ptr, 1, x.rows, x.C, 0, x.C)
 
     def relayout(self, src_ptr, dst_ptr, B, HW, Csrc, c0, Cuse, Cdst, d0, to_nchw):
@@ -222,7 +243,7 @@ class Builder:
         """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
         [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158)."""
         Np = rup(Nk, 32)
-        s = self.f32(B * Nq, Nk)
+        s = self.f32_strict(B * Nq, Nk)
         self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
                        a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)
         p = self.softmax(s, B * Nq, Nk, Nk, Np)

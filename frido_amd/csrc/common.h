@@ -66,3 +66,21 @@ __device__ __forceinline__ void store_op1(frido_bf16* op, int64_t lo_off, int ns
     op[idx] = (frido_bf16)h;
     if (nsplit == 2) op[lo_off + idx] = (frido_bf16)l;
 }
+
+// activation loads: f32 or bf16 residual stream
+__device__ __forceinline__ float4 load_act4(const void* base, int64_t idx, int is_bf16) {
+    if (is_bf16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const frido_bf16*>(base) + idx);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+__device__ __forceinline__ float load_act1(const void* base, int64_t idx, int is_bf16) {
+    if (is_bf16) return bf16_bits_to_f32(reinterpret_cast<const frido_bf16*>(base)[idx]);
+    return reinterpret_cast<const float*>(base)[idx];
+}
+__device__ __forceinline__ void store_act1(void* base, int64_t idx, int is_bf16, float v) {
+    if (is_bf16) reinterpret_cast<frido_bf16*>(base)[idx] = (frido_bf16)f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(base)[idx] = v;
+}

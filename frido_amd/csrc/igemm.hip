@@ -308,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
                 if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
                 if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
-                if (d.residual) v += d.residual[(int64_t)z * d.res_bs + (int64_t)m * d.ldr + n];
-                if (d.out_f32) d.out_f32[(int64_t)z * d.of_bs + (int64_t)m * d.ldo + n] = v;
+                if (d.residual) v += load_act1(d.residual, (int64_t)z * d.res_bs + (int64_t)m * d.ldr + n, d.res_bf16);
+                if (d.out_f32) store_act1(d.out_f32, (int64_t)z * d.of_bs + (int64_t)m * d.ldo + n, d.out_bf16, v);
                 if (d.out_op) store_op1(d.out_op + (int64_t)z * d.oo_bs, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
             }
         }
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
         if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
         if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
         else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
-        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
-        if (d.out_f32) d.out_f32[(int64_t)m * d.ldo + n] = v;
+        if (d.residual) v += load_act1(d.residual, (int64_t)m * d.ldr + n, d.res_bf16);
+        if (d.out_f32) store_act1(d.out_f32, (int64_t)m * d.ldo + n, d.out_bf16, v);
         if (d.out_op) store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
     }
 }

@@ -13,9 +13,9 @@ namespace {
 // `groups` threads reduce in double.
 constexpr int GN_MAXC = 4096;
 
-__device__ __forceinline__ float4 load_cat4(const float* x1, int C1, const float* x2, int C2, int64_t pix, int c) {
-    if (c < C1) return *reinterpret_cast<const float4*>(x1 + pix * C1 + c);
-    return *reinterpret_cast<const float4*>(x2 + pix * C2 + (c - C1));
+__device__ __forceinline__ float4 load_cat4(const float* x1, int C1, const float* x2, int C2, int64_t pix, int c, int bf) {
+    if (c < C1) return load_act4(x1, pix * C1 + c, bf);
+    return load_act4(x2, pix * C2 + (c - C1), bf);
 }
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
         if (pl < PL && c4 < C4) {
             for (int p = p0 + pl; p < p1; p += PL) {
-                const float4 v = load_cat4(d.x1, d.C1, d.x2, d.C2, (int64_t)b * d.HW + p, c4 * 4);
+                const float4 v = load_cat4(d.x1, d.C1, d.x2, d.C2, (int64_t)b * d.HW + p, c4 * 4, d.x_bf16);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
             }
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
 // GroupNorm apply: grid (blocks_per_image, B); prologue turns the partials into {mean, rstd}.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
     __shared__ float s_mean[64], s_rstd[64];
-    __shared__ double s_part[8][64][2];
+    __shared__ double s_part[8][32][2];
+    __shared__ __attribute__((aligned(16))) float s_sc[GN_MAXC], s_sh[GN_MAXC];
     const int C = d.C1 + d.C2, C4 = C >> 2;
     const int t = threadIdx.x, b = blockIdx.y;
     const int cpg = C / d.groups;
@@ -71,11 +72,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         const int g = t & 31, l8 = t >> 5;
         double s = 0.0, q = 0.0;
         if (g < d.groups) {
-            for (int sp = l8; sp < d.nsplit_px; sp += 8) {
-                const double2 p = *reinterpret_cast<const double2*>(d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + g) * 2);
-                s += p.x;
-                q += p.y;
+            double2 pv[8];        // nsplit_px <= 64: issue all (independent) loads first, then add in a fixed order
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int sp = l8 + 8 * k;
+                pv[k] = sp < d.nsplit_px
+                            ? *reinterpret_cast<const double2*>(d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + g) * 2)
+                            : make_double2(0.0, 0.0);
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += pv[k].x; q += pv[k].y; }
             s_part[l8][g][0] = s;
             s_part[l8][g][1] = q;
         }
@@ -92,30 +98,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         }
     }
     __syncthreads();
-    const int64_t total = (int64_t)d.HW * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t p = i / C4;
-        const int c = (int)(i - p * C4) * 4;
+    // per-channel scale / shift table in LDS: y = x * sc[c] + sh[c]
+    for (int c = t; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * d.weight[c];
+        s_sc[c] = sc;
+        s_sh[c] = d.bias[c] - s_mean[g] * sc;
+    }
+    __syncthreads();
+    const unsigned total = (unsigned)d.HW * (unsigned)C4;      // < 2^31 on every shape of this path
+    for (unsigned i = blockIdx.x * 256u + t; i < total; i += gridDim.x * 256u) {
+        const unsigned p = i / (unsigned)C4;
+        const int c = (int)(i - p * (unsigned)C4) * 4;
         const int64_t pix = (int64_t)b * d.HW + p;
-        const float4 v = load_cat4(d.x1, d.C1, d.x2, d.C2, pix, c);
+        const float4 v = load_cat4(d.x1, d.C1, d.x2, d.C2, pix, c, d.x_bf16);
+        const float4 sc = *reinterpret_cast<const float4*>(s_sc + c);
+        const float4 sh = *reinterpret_cast<const float4*>(s_sh + c);
         const float xin[4] = {v.x, v.y, v.z, v.w};
-        const float4 w = *reinterpret_cast<const float4*>(d.weight + c);
-        const float4 bi = *reinterpret_cast<const float4*>(d.bias + c);
-        const float ww[4] = {w.x, w.y, w.z, w.w}, bb[4] = {bi.x, bi.y, bi.z, bi.w};
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int g = (c + e) / cpg;
-            y[e] = (xin[e] - s_mean[g]) * s_rstd[g] * ww[e] + bb[e];
-        }
+        float y[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
         const int64_t o = pix * C + c;
         if (d.gamma) {
-            const float4 ga = *reinterpret_cast<const float4*>(d.gamma + o);
-            const float4 be = *reinterpret_cast<const float4*>(d.beta + o);
-            y[0] = y[0] * (1.f + ga.x) + be.x;
-            y[1] = y[1] * (1.f + ga.y) + be.y;
-            y[2] = y[2] * (1.f + ga.z) + be.z;
-            y[3] = y[3] * (1.f + ga.w) + be.w;
+            const float4 ga = load_act4(d.gamma, o, d.gb_bf16);
+            const float4 be = load_act4(d.beta, o, d.gb_bf16);
+            y[0] = fmaf(y[0], 1.f + ga.x, be.x);
+            y[1] = fmaf(y[1], 1.f + ga.y, be.y);
+            y[2] = fmaf(y[2], 1.f + ga.z, be.z);
+            y[3] = fmaf(y[3], 1.f + ga.w, be.w);
         }
         if (d.act == FRIDO_ACT_SILU) {
 #pragma unroll
@@ -133,14 +141,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= d.rows) return;
-    const float* x = d.x + (int64_t)row * d.C;
     const int C4 = d.C >> 2;
     float4 v[4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c4 = lane + i * 64;
-        v[i] = c4 < C4 ? *reinterpret_cast<const float4*>(x + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = c4 < C4 ? load_act4(d.x, (int64_t)row * d.C + c4 * 4, d.x_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / d.C;
@@ -249,8 +256,10 @@ extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
     FRIDO_REQUIRE((d->C1 & 3) == 0 && (d->C2 & 3) == 0, "channel counts must be multiples of 4");
     FRIDO_REQUIRE(d->out_op || d->out_f32, "no output");
     FRIDO_REQUIRE((d->gamma == nullptr) == (d->beta == nullptr), "gamma/beta must come together");
+    FRIDO_REQUIRE(C <= GN_MAXC && (int64_t)d->HW * (C >> 2) < (1ll << 31), "tensor too large for the 32-bit index path");
     const int64_t per_img = (int64_t)d->HW * (C >> 2);
-    int gx = grid_for(per_img, 2048 / (d->B < 2048 ? d->B : 2048) + 8);
+    FRIDO_REQUIRE(d->nsplit_px <= 64, "at most 64 pixel splits");
+    int gx = grid_for(per_img, 1536 / (d->B < 1536 ? d->B : 1536) + 8);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("gn_apply");
 }

@@ -107,23 +107,47 @@ class Pool:
 
 
 class F32:
-    """f32 activation [rows][C] living in a pooled buffer."""
+    """Activation [rows][C] of the residual stream in a pooled buffer: f32, or (bf16 = True) a single bf16 plane that
+    doubles as an MFMA operand (K = C)."""
 
-    def __init__(self, pool, rows, C):
-        self.rows, self.C, self.pool = rows, C, pool
-        self.buf = pool.alloc(rows * C * 4)
+    def __init__(self, pool, rows, C, bf16=False):
+        self.rows, self.C, self.pool, self.bf16 = rows, C, pool, bf16
+        self.K, self.lo, self.nsplit, self.batch = C, 0, 1, 1       # operand view (valid when bf16)
+        self.buf = pool.alloc(rows * C * (2 if bf16 else 4))
 
     @property
     def ptr(self):
         return self.buf.data_ptr()
 
     def view(self):
-        return self.buf[: self.rows * self.C * 4].view(torch.float32).view(self.rows, self.C)
+        dt, nb = (torch.bfloat16, 2) if self.bf16 else (torch.float32, 4)
+        return self.buf[: self.rows * self.C * nb].view(dt).view(self.rows, self.C)
+
+    def to_f32(self):
+        return self.view().float()
 
     def free(self):
         if self.buf is not None:
             self.pool.release(self.buf)
             self.buf = None
+
+
+class Alias:
+    """Non-owning operand view of a bf16 activation (free() is a no-op)."""
+
+    def __init__(self, act):
+        self.act = act
+        self.rows, self.K, self.lo, self.nsplit, self.batch = act.rows, act.C, 0, 1, 1
+
+    @property
+    def ptr(self):
+        return self.act.ptr
+
+    def to_f32(self):
+        return self.act.to_f32()
+
+    def free(self):
+        pass
 
 
 class POperand:
@@ -170,7 +194,7 @@ class Prog:
     def gemm(self, M, N, K, A, B, *, batch=1, lda=None, ldb=None, a_bs=0, b_bs=0, a_lo=None, b_lo=None,
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
              residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
-             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0):
+             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0):
         """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
         ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
@@ -188,9 +212,9 @@ class Prog:
             if rowvec_step is not None:
                 kw["rowvec_step"] = rowvec_step
         if residual is not None:
-            kw.update(residual=residual, res_bs=res_bs, ldr=ldr)
+            kw.update(residual=residual, res_bs=res_bs, ldr=ldr, res_bf16=int(res_bf16))
         if out_f32 is not None:
-            kw.update(out_f32=out_f32, of_bs=of_bs, ldo=ldo)
+            kw.update(out_f32=out_f32, of_bs=of_bs, ldo=ldo, out_bf16=int(out_bf16))
         if out_op is not None:
             kw.update(out_op=out_op, oo_bs=oo_bs, ldoo=ldoo, oo_lo=oo_lo)
         self.emit("FRIDO_OP_GEMM", **kw)

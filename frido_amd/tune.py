@@ -15,7 +15,7 @@ ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
 
 _SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
                "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
-               "res_bs")
+               "res_bs", "res_bf16", "out_bf16")
 
 
 def _buf(name, nbytes, device):

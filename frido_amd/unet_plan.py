@@ -66,6 +66,16 @@ class UNetStagePlan:
         def free(self):
             pass
 
+    def _persistent_act(self, rows, C):
+        """Persistent [rows][C] activation in the stream dtype (bf16 in bf16 mode, f32 in bf16x3 mode)."""
+        b = self.b
+        dt = torch.bfloat16 if b.stream_bf16 else torch.float32
+        t = torch.empty(rows, C, dtype=dt, device=b.device)
+        b._persist.append(t)
+        w = self._T(t)
+        w.bf16 = b.stream_bf16
+        return w
+
     def _pack_x(self, c0, c1):
         """operand [Bx*HW][32] of latent channels [c0, c1) (replicated xrep times)."""
         b, HW = self.b, self.H * self.W
@@ -82,9 +92,9 @@ class UNetStagePlan:
         mc, te = a.model_channels, a.time_embed_dim
         # ---- timestep / stage embedding table (util.py:151-171, pyunet.py:560-565,882-896) ----
         n = self.temb_rows
-        sin = b.f32(n, mc)
+        sin = b.f32_strict(n, mc)
         prog.emit("FRIDO_OP_TIME_EMB", t=self.t_dev.data_ptr(), n=n, dim=mc, max_period=10000.0, out=sin.ptr)
-        sin_op = b.to_operand(sin)
+        sin_op = b.pack(sin.ptr, 1, n, mc, 0, mc)
         sin.free()
         h1 = b.linear(sin_op, "time_embed.0", act=ACT_SILU, out="op")
         sin_op.free()
@@ -122,8 +132,8 @@ class UNetStagePlan:
             for name, C, lvl in self._spade_sites():
                 Hl, Wl = self.H >> lvl, self.W >> lvl
                 actv = b.conv(hc, self.Bx, self.H, self.W, name + ".mlp_shared.0", dn=lvl, act=ACT_RELU, out="op")
-                g = self._T(b.persistent_f32(self.Bx * Hl * Wl, C))
-                be = self._T(b.persistent_f32(self.Bx * Hl * Wl, C))
+                g = self._persistent_act(self.Bx * Hl * Wl, C)
+                be = self._persistent_act(self.Bx * Hl * Wl, C)
                 b.conv(actv, self.Bx, Hl, Wl, name + ".mlp_gamma", out=("f32", g))
                 b.conv(actv, self.Bx, Hl, Wl, name + ".mlp_beta", out=("f32", be))
                 actv.free()

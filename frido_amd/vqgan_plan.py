@@ -50,7 +50,7 @@ class VQDecodePlan:
                       q0=sum(embed_dim[i + 1:]), idx=self.idx[i].data_ptr())
             start += e
         q_op = b.pack(self.quant.data_ptr(), 1, B * hw, Ct, 0, Ct)
-        pq = b.linear(q_op, "post_quant_conv")
+        pq = b.linear(q_op, "post_quant_conv", out="f32_strict")
         q_op.free()
         z_op = b.pack(pq.ptr, 1, B * hw, pq.C, 0, pq.C)
         pq.free()

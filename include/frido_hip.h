@@ -70,6 +70,7 @@ typedef struct FridoGemm {
                                    (a) * gelu_erf(gate) as an operand [M][N/2] (attention.py:42-44), no f32 output */
     const float* residual; int64_t res_bs; int32_t ldr;
     float* out_f32; int64_t of_bs; int32_t ldo;
+    int32_t res_bf16, out_bf16; /* 1: `residual` / `out_f32` point at bf16 activations (bf16 residual stream) */
     frido_bf16* out_op; int64_t oo_lo; int64_t oo_bs; int32_t ldoo;
     int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to `ws` [splitk][M][N] f32 and a
                                    second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
@@ -79,12 +80,15 @@ typedef struct FridoGemm {
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two
  * NHWC f32 tensors: nn.GroupNorm call sites util.py:214-216 (eps 1e-5), attention.py:76-77 and
- * taming/.../model.py:34-35 (eps 1e-6); the concat is pyunet.py:939.  Writes per-(b, split, group)
- * partial {sum, sumsq} as doubles: partials[b][s][g][2]; the consumer combines them. */
+ * taming/.../model.py:34-35 (eps 1e-6); the concat is pyunet.py:939.  Each (b, pixel-split) workgroup writes
+ * per-group partial {sum, sumsq} doubles to partials[b][s][g][2]; frido_gn_apply combines them in a fixed order.
+ * (A last-arriver finalise inside this kernel was measured: the agent-scope release fence per workgroup costs 3x
+ * what it saves — MI355X_MICROARCH.md price list, `buffer_wbl2` with dirty L2 — so the combine lives in apply.) */
 typedef struct FridoGnStats {
     const float* x1; int32_t C1; const float* x2; int32_t C2;
     int32_t B, HW, groups, nsplit_px;
     double* partials;
+    int32_t x_bf16;             /* 1: x1 / x2 are bf16 */
 } FridoGnStats;
 
 /* GroupNorm apply (+ SPADE modulation + SiLU) -> operand tensor.
@@ -102,6 +106,8 @@ typedef struct FridoGnApply {
     frido_bf16* out_op; int64_t out_lo;
     frido_bf16* raw_op; int64_t raw_lo;
     float* out_f32;
+    int32_t x_bf16;             /* 1: x1 / x2 are bf16 */
+    int32_t gb_bf16;            /* 1: gamma / beta are bf16 */
 } FridoGnApply;
 
 /* LayerNorm over the last dim (eps 1e-5, affine): attention.py:203-205 -> operand tensor. */
@@ -109,6 +115,7 @@ typedef struct FridoLayerNorm {
     const float* x; int32_t rows, C; float eps;
     const float* weight; const float* bias;
     int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
+    int32_t x_bf16;
 } FridoLayerNorm;
 
 /* Row softmax (attention.py:188, taming model.py:181): x[rows][N] f32 (ld) -> operand [rows][Npad]

@@ -190,6 +190,33 @@ def test_groupnorm_apply(C1, C2, HW, spade):
     assert _relerr(raw.to_f32().cpu(), xc.reshape(B * HW, C)) < 2e-5
 
 
+def test_bf16_residual_stream_inputs():
+    """bf16 mode keeps the residual stream in bf16: GroupNorm / LayerNorm / residual epilogue read it directly."""
+    from frido_amd.builder import ACT_SILU
+    B, HW, C = 2, 64, 96
+    x = _t("bx", B * HW, C).to(torch.bfloat16).float()          # exactly representable inputs
+    w, bi = 1 + 0.1 * _t("bw", C), 0.1 * _t("bb", C)
+    b = _builder(1, {"n.weight": w.cuda(), "n.bias": bi.cuda(), "l.weight": _t("blw", 64, C).cuda() / 10, "l.bias": _t("blb", 64).cuda()})
+    assert b.stream_bf16
+    f = b.f32(B * HW, C)
+    assert f.bf16
+    f.view().copy_(x.cuda())
+    r = b.f32(B * HW, 64)        # allocate every eagerly-filled buffer BEFORE emitting ops (the pool recycles scratch)
+    r.view().copy_(_t("br", B * HW, 64).cuda())
+    res_ref = r.view().float().cpu()
+    a, raw = b.groupnorm(f, None, B, HW, "n", 1e-5, act=ACT_SILU, want_raw=True)
+    ln = b.layernorm(f, "n")
+    y = b.linear(raw, "l", residual=r)
+    _run(b)
+    xn = x.view(B, HW, C).permute(0, 2, 1).reshape(B, C, HW, 1)
+    ref = F.silu(F.group_norm(xn, 32, w, bi, 1e-5)).reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
+    assert _relerr(a.to_f32().cpu(), ref) < 1e-2
+    assert torch.equal(raw.to_f32().cpu(), x)                    # alias: the activation is its own operand
+    assert _relerr(ln.to_f32().cpu(), F.layer_norm(x, (C,), w, bi, 1e-5)) < 1e-2
+    yref = x @ (b.w["l.weight"].cpu().t()) + b.w["l.bias"].cpu() + res_ref
+    assert y.bf16 and _relerr(y.to_f32().cpu(), yref) < 2e-2
+
+
 @pytest.mark.parametrize("C", [64, 384, 576, 960])
 def test_layernorm(C):
     rows = 37
