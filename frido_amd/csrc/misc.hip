@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void relayout_kernel(const FridoRelayout d) {
         const int64_t bc = i / d.HW;
         const int c = (int)(bc % d.Cuse);
         const int64_t b = bc / d.Cuse;
-        if (d.to_nchw)
+        if (d.to_nchw == 2)      // NHWC -> NHWC column block copy
+            d.dst[(b * d.HW + p) * d.Cdst + d.d0 + c] = d.src[(b * d.HW + p) * d.Csrc + d.c0 + c];
+        else if (d.to_nchw)
             d.dst[(b * d.Cdst + d.d0 + c) * d.HW + p] = d.src[(b * d.HW + p) * d.Csrc + d.c0 + c];
         else
             d.dst[(b * d.HW + p) * d.Cdst + d.d0 + c] = d.src[(b * d.Csrc + d.c0 + c) * d.HW + p];
@@ -247,6 +249,44 @@ __global__ __launch_bounds__(256) void time_emb_kernel(const FridoTimeEmb d) {
     }
 }
 
+__global__ __launch_bounds__(256) void convt_kernel(const FridoConvT d) {
+    const int H = d.h * 2, W = d.w * 2;
+    const int64_t total = (int64_t)d.B * H * W * d.Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % d.Cout);
+        int64_t r = i / d.Cout;
+        const int ox = (int)(r % W); r /= W;
+        const int oy = (int)(r % H);
+        const int64_t b = r / H;
+        float acc = d.bias ? d.bias[co] : 0.f;
+        for (int ky = 0; ky < 4; ++ky) {
+            const int ty = oy + 1 - ky;                 // oy = iy*2 - 1 + ky
+            if (ty < 0 || (ty & 1) || (ty >> 1) >= d.h) continue;
+            for (int kx = 0; kx < 4; ++kx) {
+                const int tx = ox + 1 - kx;
+                if (tx < 0 || (tx & 1) || (tx >> 1) >= d.w) continue;
+                const float* px = d.src + ((b * d.h + (ty >> 1)) * d.w + (tx >> 1)) * d.Cin;
+                for (int ci = 0; ci < d.Cin; ++ci) acc = fmaf(px[ci], d.weight[((ci * d.Cout + co) * 4 + ky) * 4 + kx], acc);
+            }
+        }
+        d.dst[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void place_kernel(const FridoPlace d) {
+    const int H = d.h << d.up_shift, W = d.w << d.up_shift;
+    const int64_t total = (int64_t)d.B * d.Cuse * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % W);
+        int64_t r = i / W;
+        const int oy = (int)(r % H); r /= H;
+        const int c = (int)(r % d.Cuse);
+        const int64_t b = r / d.Cuse;
+        const float v = d.src[((b * d.h + (oy >> d.up_shift)) * d.w + (ox >> d.up_shift)) * d.Csrc + d.c0 + c];
+        d.dst[((b * d.Cdst + d.d0 + c) * H + oy) * W + ox] = v * d.scale;
+    }
+}
+
 __global__ void step_add_kernel(const FridoStepAdd d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *d.step += d.delta;
 }
@@ -313,6 +353,19 @@ extern "C" int frido_time_emb(const FridoTimeEmb* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->t && d->out && d->n > 0 && d->dim >= 2, "bad arguments");
     hipLaunchKernelGGL(time_emb_kernel, dim3(grid_for((int64_t)d->n * (d->dim / 2))), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("time_emb");
+}
+
+extern "C" int frido_convt(const FridoConvT* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->src && d->dst && d->weight && d->Cin > 0 && d->Cout > 0 && d->B > 0, "bad arguments");
+    hipLaunchKernelGGL(convt_kernel, dim3(grid_for((int64_t)d->B * d->h * d->w * 4 * d->Cout)), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("convt");
+}
+
+extern "C" int frido_place(const FridoPlace* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->src && d->dst && d->Cuse > 0 && d->c0 + d->Cuse <= d->Csrc && d->d0 + d->Cuse <= d->Cdst, "bad arguments");
+    hipLaunchKernelGGL(place_kernel, dim3(grid_for(((int64_t)d->B * d->Cuse * d->h * d->w) << (2 * d->up_shift))), dim3(256), 0,
+                       (hipStream_t)s, *d);
+    return frido_check_launch("place");
 }
 
 extern "C" int frido_fill(const FridoFill* d, frido_stream_t s) {

@@ -49,6 +49,8 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_STEP_ADD: return frido_step_add(&op.u.step_add, s);
         case FRIDO_OP_FILL: return frido_fill(&op.u.fill, s);
         case FRIDO_OP_TIME_EMB: return frido_time_emb(&op.u.time_emb, s);
+        case FRIDO_OP_CONVT: return frido_convt(&op.u.convt, s);
+        case FRIDO_OP_PLACE: return frido_place(&op.u.place, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -220,6 +222,8 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_STEP_ADD: return sizeof(FridoStepAdd);
         case FRIDO_OP_FILL: return sizeof(FridoFill);
         case FRIDO_OP_TIME_EMB: return sizeof(FridoTimeEmb);
+        case FRIDO_OP_CONVT: return sizeof(FridoConvT);
+        case FRIDO_OP_PLACE: return sizeof(FridoPlace);
         default: return -1;
     }
 }

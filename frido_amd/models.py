@@ -227,9 +227,13 @@ class VQModelInterface(_Versioned, _Base):
             return dec, [i.tolist() for i in idx]     # the reference's host lists (msvqgan.py:390)
         return out
 
-    def encode(self, x):
-        raise FridoHipError("VQModelInterface.encode (SURVEY.md §8 a16) is not on the HIP path yet — next row of the "
-                            "scope table; sampling from random latents does not need it")
+    @torch.no_grad()
+    def encode(self, x, scale=None):
+        """msvqgan.py:326-374: image (B,3,H,W) -> pre-quant multi-scale latent, channels [coarse .. fine]."""
+        if not x.is_cuda:
+            _no_cpu("VQModelInterface.encode", x.device)
+        assert len(self.channel_range) != 2, "channel_range slicing is not used by any shipped config"
+        return self.runtime().encode(x, scale=scale)
 
 
 # ---- EMA shadow (frido/modules/ema.py) ---------------------------------------------------------------
@@ -424,8 +428,39 @@ class FridoDiffusion(_Base):
             inv = [float(np.float32(1.0) / np.float32(v)) for v in sfs]
         return self.first_stage_model.decode(z_in, return_code=return_code, inv_scale=inv)
 
+    @torch.no_grad()
     def encode_first_stage(self, x):
+        """frido.py:962-1005 (no split_input_params; the reference's duplicated encode call is not repeated)."""
         return self.first_stage_model.encode(x)
+
+    @torch.no_grad()
+    def get_input(self, batch, k, return_first_stage_outputs=False, force_c_encode=False, cond_key=None,
+                  return_original_cond=False, bs=None):
+        """frido.py:767-816 for the inference callers (scripts/sample_diffusion.py:236-240): returns [z, c, (x, xrec), (xc)]."""
+        x = batch[k]
+        if x.dim() == 3:
+            x = x[..., None]
+        x = x.permute(0, 3, 1, 2).contiguous().float()          # 'b h w c -> b c h w' (frido.py:372-380)
+        if bs is not None:
+            x = x[:bs]
+        x = x.to(self.device)
+        sf = self.scale_factor.detach().float().cpu().numpy() if torch.is_tensor(self.scale_factor) else [float(self.scale_factor)]
+        n = len(self.first_stage_model.embed_dim)
+        scale = [float(sf[i] if len(sf) > 1 else sf[0]) for i in range(n)]
+        z = self.first_stage_model.encode(x, scale=scale)        # encode + get_first_stage_encoding fused
+        c = None
+        if self.model.conditioning_key is not None:
+            ck = cond_key or self.cond_stage_key
+            xc = batch[ck] if ck != self.first_stage_key else x
+            if bs is not None and torch.is_tensor(xc):
+                xc = xc[:bs]
+            c = self.get_learned_conditioning(xc.to(self.device) if torch.is_tensor(xc) else xc) if force_c_encode or not self.cond_stage_trainable else xc
+        out = [z, c]
+        if return_first_stage_outputs:
+            out.extend([x, self.decode_first_stage(z)])
+        if return_original_cond:
+            out.append(xc)
+        return out
 
     def forward(self, *a, **k):
         raise FridoHipError("training (FridoDiffusion.forward / p_losses) is outside the inference hot path")

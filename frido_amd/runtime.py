@@ -14,7 +14,7 @@ from .builder import Builder
 from .engine import current_stream_ptr, require_gpu
 from .schedules import sampler_coef_table, COEF_ROW
 from .unet_plan import UNetStagePlan
-from .vqgan_plan import VQDecodePlan
+from .vqgan_plan import VQDecodePlan, VQEncodePlan
 
 
 def _weights_of(module, device):
@@ -322,3 +322,19 @@ class DecoderRuntime:
         if return_code:
             return out, [i.view(B, -1) for i in plan.idx]
         return out
+
+    def encode(self, x, scale=None):
+        """x (B, 3, H, W) NCHW image -> pre-quantisation latent (B, sum(embed), H/f, W/f); `scale` (per scale) folds
+        get_first_stage_encoding's multiply in."""
+        B, Cin, H, W = x.shape
+        embed = self.cfg["embed_dim"]
+        sc = tuple(float(v) for v in (scale if scale is not None else [1.0] * len(embed)))
+        key = ("enc", B, H, W, sc)
+        st = current_stream_ptr(self.device)
+        if key not in self.plans:
+            x_in = torch.zeros(B, Cin, H, W, dtype=torch.float32, device=self.device)
+            self.plans[key] = (x_in, VQEncodePlan(self.b, self.cfg, B=B, H=H, W=W, x_in=x_in, scale=sc))
+        x_in, plan = self.plans[key]
+        x_in.copy_(x)            # plumbing: D2D copy into the plan's fixed input buffer
+        plan.prog.run(st)
+        return plan.out.clone()

@@ -26,6 +26,85 @@ class _T:
         pass
 
 
+def vq_res(b, B, blk_prefix, x, h, w):
+    """taming ResnetBlock (model.py:117-137, temb None, eps 1e-6) on an NHWC activation."""
+    HW = h * w
+    pre = blk_prefix
+    has_nin = (pre + ".nin_shortcut.weight") in b.w
+    a1, raw = b.groupnorm(x, None, B, HW, pre + ".norm1", 1e-6, act=ACT_SILU, want_raw=has_nin)
+    hmid = b.conv(a1, B, h, w, pre + ".conv1")
+    a1.free()
+    a2, _ = b.groupnorm(hmid, None, B, HW, pre + ".norm2", 1e-6, act=ACT_SILU)
+    hmid.free()
+    if has_nin:
+        res = b.linear(raw, pre + ".nin_shortcut")
+        raw.free()
+        out = b.conv(a2, B, h, w, pre + ".conv2", residual=res, out=("f32", res))
+    else:
+        out = b.conv(a2, B, h, w, pre + ".conv2", residual=x)
+    a2.free()
+    return out
+
+
+def vq_attn(b, B, blk_prefix, C, x, h, w):
+    """taming AttnBlock (model.py:168-192): biased 1x1 q/k/v, single head, softmax over keys, proj_out + residual."""
+    HW = h * w
+    pre = blk_prefix
+    a0, _ = b.groupnorm(x, None, B, HW, pre + ".norm", 1e-6, act=ACT_NONE)
+    wqk = b.cat_lin_weight(("vqk", pre), [pre + ".q.weight", pre + ".k.weight"])
+    key = ("vqk_bias", pre)
+    if key not in b._wcache:
+        b._wcache[key] = torch.cat([b.w[pre + ".q.bias"].float(), b.w[pre + ".k.bias"].float()]).contiguous()
+    qk = b.op(B * HW, 2 * C)
+    b.linear(a0, None, wop=wqk, bias_ptr=b._wcache[key].data_ptr(), out=("op", qk))
+    vkey = ("vT", C, HW, B)
+    if vkey not in b._wcache:
+        b._wcache[vkey] = b.persistent_op(C, rup(HW, 32), batch=B, zero=True)
+    vT = b._wcache[vkey]
+    b.v_transposed(a0, C, b.lin_weight(pre + ".v.weight"), B, HW, C, bias_ptr=b.bias(pre + ".v.bias"), out=vT)
+    a0.free()
+    o = b.attention(qk, 2 * C, qk, 2 * C, vT, B, HW, HW, C, q_off=0, k_off=C)
+    qk.free()
+    out = b.linear(o, pre + ".proj_out", residual=x)
+    o.free()
+    return out
+
+
+def vq_run_blocks(b, B, blocks, cur, h, w, keep=()):
+    """Run a list of VBlk on `cur`; returns (out, h, w).  `cur` is freed unless it is in `keep`."""
+    for blk in blocks:
+        if blk.kind == "res":
+            nxt = vq_res(b, B, blk.prefix, cur, h, w)
+        elif blk.kind == "attn":
+            nxt = vq_attn(b, B, blk.prefix, blk.cin, cur, h, w)
+        elif blk.kind == "up":       # model.py:49-53
+            xo = b.to_operand(cur)
+            nxt = b.conv(xo, B, h, w, blk.prefix + ".conv", up=1)
+            xo.free()
+            h, w = h * 2, w * 2
+        else:                        # 'down' (model.py:68-72): zero-pad right/bottom by one, conv3x3 stride 2 pad 0
+            xo = b.to_operand(cur)
+            nxt = b.conv(xo, B, h, w, blk.prefix + ".conv", stride=2, pad=0, Ho=h // 2, Wo=w // 2)
+            xo.free()
+            h, w = h // 2, w // 2
+        if not any(cur is k for k in keep):
+            cur.free()
+        cur = nxt
+    return cur, h, w
+
+
+def decoder_body(b, B, dd, prefix, z_op, h, w, out):
+    """Decoder.forward (model.py:618-649) from an operand latent to `out` (("f32", buffer) or "f32_strict")."""
+    a = decoder_arch(dd, prefix)
+    cur = b.conv(z_op, B, h, w, prefix + ".conv_in")
+    cur, h, w = vq_run_blocks(b, B, a.body, cur, h, w)
+    ao, _ = b.groupnorm(cur, None, B, h * w, prefix + ".norm_out", 1e-6, act=ACT_SILU)
+    cur.free()
+    res = b.conv(ao, B, h, w, prefix + ".conv_out", out=out)
+    ao.free()
+    return res, h, w
+
+
 class VQDecodePlan:
     def __init__(self, b: Builder, ddconfig, embed_dim, n_embed, *, B, h, w, z_state, inv_scale):
         """z_state: device f32 [B][h*w][sum(embed_dim)] NHWC latent (already in diffusion scale);
@@ -54,59 +133,111 @@ class VQDecodePlan:
         q_op.free()
         z_op = b.pack(pq.ptr, 1, B * hw, pq.C, 0, pq.C)
         pq.free()
-        cur = b.conv(z_op, B, h, w, "decoder.conv_in")
+        decoder_body(b, B, ddconfig, "decoder", z_op, h, w, ("f32", _T(self.out_nhwc)))
         z_op.free()
-        ch, cw = h, w
-        for blk in a.body:
-            if blk.kind == "res":
-                nxt = self._res(blk, cur, ch, cw)
-            elif blk.kind == "attn":
-                nxt = self._attn(blk, cur, ch, cw)
-            else:  # up
-                xo = b.to_operand(cur)
-                nxt = b.conv(xo, B, ch, cw, blk.prefix + ".conv", up=1)
-                xo.free()
-                ch, cw = ch * 2, cw * 2
-            cur.free()
-            cur = nxt
-        ao, _ = b.groupnorm(cur, None, B, ch * cw, "decoder.norm_out", 1e-6, act=ACT_SILU)
-        cur.free()
-        b.conv(ao, B, ch, cw, "decoder.conv_out", out=("f32", _T(self.out_nhwc)))
-        ao.free()
 
-    def _res(self, blk, x, h, w):
-        b, B, HW = self.b, self.B, h * w
-        pre = blk.prefix
-        has_nin = (pre + ".nin_shortcut.weight") in b.w
-        a1, raw = b.groupnorm(x, None, B, HW, pre + ".norm1", 1e-6, act=ACT_SILU, want_raw=has_nin)
-        hmid = b.conv(a1, B, h, w, pre + ".conv1")
-        a1.free()
-        a2, _ = b.groupnorm(hmid, None, B, HW, pre + ".norm2", 1e-6, act=ACT_SILU)
-        hmid.free()
-        if has_nin:
-            res = b.linear(raw, pre + ".nin_shortcut")
-            raw.free()
-            out = b.conv(a2, B, h, w, pre + ".conv2", residual=res, out=("f32", res))
-        else:
-            out = b.conv(a2, B, h, w, pre + ".conv2", residual=x)
-        a2.free()
-        return out
 
-    def _attn(self, blk, x, h, w):
-        b, B, HW, C = self.b, self.B, h * w, blk.cin
-        pre = blk.prefix
-        a0, _ = b.groupnorm(x, None, B, HW, pre + ".norm", 1e-6, act=ACT_NONE)
-        wqk = b.cat_lin_weight(("vqk", pre), [pre + ".q.weight", pre + ".k.weight"])
-        key = ("vqk_bias", pre)
-        if key not in b._wcache:
-            b._wcache[key] = torch.cat([b.w[pre + ".q.bias"].float(), b.w[pre + ".k.bias"].float()]).contiguous()
-        qk = b.op(B * HW, 2 * C)
-        b.linear(a0, None, wop=wqk, bias_ptr=b._wcache[key].data_ptr(), out=("op", qk))
-        vT = b.persistent_op(C, rup(HW, 32), batch=B, zero=True)
-        b.v_transposed(a0, C, b.lin_weight(pre + ".v.weight"), B, HW, C, bias_ptr=b.bias(pre + ".v.bias"), out=vT)
-        a0.free()
-        o = b.attention(qk, 2 * C, qk, 2 * C, vT, B, HW, HW, C, q_off=0, k_off=C)
-        qk.free()
-        out = b.linear(o, pre + ".proj_out", residual=x)
-        o.free()
-        return out
+class VQEncodePlan:
+    """VQModelInterface.encode (msvqgan.py:326-374): MSEncoder (model.py:512-546) -> coarse-to-fine pre-quant features
+    (quant_conv, VQ, ConvTranspose upsample, shared decoder) -> nearest-upsampled channel concat [coarse .. fine],
+    optionally scaled per scale like get_first_stage_encoding (frido.py:654-662)."""
+
+    def __init__(self, b: Builder, vq_cfg, *, B, H, W, x_in, scale):
+        from .arch import encoder_arch
+        from .holders import shared_decoder_cfg
+        self.b = b
+        ed, embed, n_embed = vq_cfg["edconfig"], vq_cfg["embed_dim"], vq_cfg["n_embed"]
+        a = encoder_arch(ed, "encoder")
+        n = a.multiscale
+        dev = b.device
+        prog = self.prog = b.new_prog()
+        x_op = b.pack(x_in.data_ptr(), B, H * W, ed["in_channels"], 0, ed["in_channels"], nchw=True)
+        cur = b.conv(x_op, B, H, W, "encoder.conv_in")
+        x_op.free()
+        h, w = H, W
+        level_out = []
+        nlev = len(a.down)
+        for li, blocks in enumerate(a.down):
+            body = [blk for blk in blocks if blk.kind != "down"]
+            cur, h, w = vq_run_blocks(b, B, body, cur, h, w)
+            kept = li >= nlev - n          # the last `multiscale` level outputs feed the heads (model.py:525-531)
+            if kept:
+                level_out.append((cur, h, w))
+            downs = [blk for blk in blocks if blk.kind == "down"]
+            if downs:
+                cur, h, w = vq_run_blocks(b, B, downs, cur, h, w, keep=[cur] if kept else [])
+        # heads (fine first, like the reference's out_h); h_ms = reversed -> coarse first
+        heads = []
+        for i in range(n):
+            feat, fh, fw = level_out[-(n - i)]
+            hcur, _, _ = vq_run_blocks(b, B, a.heads[i], feat, fh, fw, keep=[feat])
+            ao, _ = b.groupnorm(hcur, None, B, fh * fw, f"encoder.norm_out_ms.{i}", 1e-6, act=ACT_SILU)
+            hcur.free()
+            heads.append((ao, fh, fw, a.z_channels[i]))
+        heads = heads[::-1]          # coarse first
+        self.h_out = []
+        prev = []                    # quantised maps of coarser scales: (f32 tensor [B*hw][e], h, w)
+        for ii in range(n):
+            ao, fh, fw, zc = heads[ii]
+            hw = fh * fw
+            if ii == 0:
+                feat = b.conv(ao, B, fh, fw, f"encoder.conv_out_ms.{n - 1 - ii}", out="f32_strict")
+                ao.free()
+                q_in, q_c = feat, zc
+            else:
+                ctot = sum(embed[:ii]) + zc
+                cat = torch.zeros(B * hw, ctot, dtype=torch.float32, device=dev)
+                b._persist.append(cat)
+                col = 0
+                for j in range(ii):          # msvqgan.py:334-337: every coarser quant is upsampled again at each scale
+                    pt, ph, pw = prev[j]
+                    up = torch.zeros(B * ph * pw * 4, embed[0], dtype=torch.float32, device=dev)
+                    b._persist.append(up)
+                    prog.emit("FRIDO_OP_CONVT", src=pt.data_ptr(), dst=up.data_ptr(), weight=b.dev_f32(f"upsample.{ii - 1}.weight").data_ptr(),
+                              bias=b.bias(f"upsample.{ii - 1}.bias"), B=B, h=ph, w=pw, Cin=embed[0], Cout=embed[0])
+                    up_op = b.pack(up.data_ptr(), 1, B * ph * pw * 4, embed[0], 0, embed[0])
+                    pq = torch.zeros(B * ph * pw * 4, ed["z_channels"][0], dtype=torch.float32, device=dev)
+                    b._persist.append(pq)
+                    b.linear(up_op, f"shared_post_quant_conv.{ii - 1}", out=("f32", _T(pq)))
+                    up_op.free()
+                    prev[j] = (pq, ph * 2, pw * 2)
+                    assert (ph * 2, pw * 2) == (fh, fw)
+                    prog.emit("FRIDO_OP_RELAYOUT", src=pq.data_ptr(), dst=cat.data_ptr(), B=1, HW=B * hw, Csrc=pq.shape[1], c0=0,
+                              Cuse=pq.shape[1], Cdst=ctot, d0=col, to_nchw=2)
+                    col += pq.shape[1]
+                fine = _T(torch.zeros(B * hw, zc, dtype=torch.float32, device=dev))
+                b._persist.append(fine.t)
+                b.conv(ao, B, fh, fw, f"encoder.conv_out_ms.{n - 1 - ii}", out=("f32", fine))
+                ao.free()
+                prog.emit("FRIDO_OP_RELAYOUT", src=fine.ptr, dst=cat.data_ptr(), B=1, HW=B * hw, Csrc=zc, c0=0, Cuse=zc, Cdst=ctot,
+                          d0=col, to_nchw=2)
+                cat_op = b.pack(cat.data_ptr(), 1, B * hw, ctot, 0, ctot)
+                sd, _, _ = decoder_body(b, B, shared_decoder_cfg(embed, ii - 1), f"shared_decoder.{ii - 1}", cat_op, fh, fw,
+                                        "f32_strict")
+                cat_op.free()
+                q_in, q_c = sd, embed[0]
+            q_op = b.pack(q_in.ptr, 1, B * hw, q_c, 0, q_c)
+            q_in.free()
+            hq = torch.zeros(B * hw, embed[ii], dtype=torch.float32, device=dev)
+            b._persist.append(hq)
+            b.linear(q_op, f"ms_quant_conv.{ii}", out=("f32", _T(hq)))
+            q_op.free()
+            self.h_out.append((hq, fh, fw))
+            if ii < n - 1:
+                zq = torch.zeros(B * hw, embed[ii], dtype=torch.float32, device=dev)
+                b._persist.append(zq)
+                cb = b.dev_f32(f"ms_quantize.{ii}.embedding.weight")
+                prog.emit("FRIDO_OP_VQ", x=hq.data_ptr(), npix=B * hw, Cx=embed[ii], c0=0, e=embed[ii], inv_scale=1.0,
+                          codebook=cb.data_ptr(), n_codes=n_embed[ii], zq=zq.data_ptr(), Cq=embed[ii], q0=0, idx=None)
+                prev.append((zq, fh, fw))
+        for t, _, _ in level_out:
+            t.free()
+        # channel concat [coarse, ..., fine], every scale nearest-upsampled to the finest grid
+        fh, fw = self.h_out[-1][1], self.h_out[-1][2]
+        self.out = torch.zeros(B, sum(embed), fh, fw, dtype=torch.float32, device=dev)
+        d0 = 0
+        for i, (hq, hh, ww) in enumerate(self.h_out):
+            up = (fh // hh).bit_length() - 1
+            prog.emit("FRIDO_OP_PLACE", src=hq.data_ptr(), dst=self.out.data_ptr(), B=B, h=hh, w=ww, Csrc=embed[i], c0=0,
+                      Cuse=embed[i], Cdst=sum(embed), d0=d0, up_shift=up, scale=float(scale[i]))
+            d0 += embed[i]

@@ -141,7 +141,7 @@ typedef struct FridoPack {
 } FridoPack;
 
 /* f32 layout change: NHWC [B][HW][Csrc] columns [c0, c0+Cuse) -> NCHW dst[B][Cdst][HW] at channel d0,
- * or the reverse direction (to_nchw = 0: NCHW src -> NHWC dst). */
+ * or the reverse direction (to_nchw = 0: NCHW src -> NHWC dst), or an NHWC -> NHWC column-block copy (to_nchw = 2). */
 typedef struct FridoRelayout {
     const float* src; float* dst;
     int32_t B, HW, Csrc, c0, Cuse, Cdst, d0, to_nchw;
@@ -199,6 +199,17 @@ typedef struct FridoRandn {
  * all in fp32 like the reference; t is int64 (DDPM indices). */
 typedef struct FridoTimeEmb { const int64_t* t; int32_t n, dim; float max_period; float* out; } FridoTimeEmb;
 
+/* ConvTranspose2d(k=4, stride=2, padding=1) on small-channel f32 NHWC maps (taming/models/msvqgan.py:81-83, the
+ * coarse-to-fine `upsample` of the MS-VQGAN encoder): src [B][h][w][Cin] -> dst [B][2h][2w][Cout] (+bias);
+ * weight in nn.ConvTranspose2d layout [Cin][Cout][4][4]. */
+typedef struct FridoConvT { const float* src; float* dst; const float* weight; const float* bias;
+                            int32_t B, h, w, Cin, Cout; } FridoConvT;
+
+/* Nearest 2^up_shift up-sampling of channels [c0, c0+Cuse) of an NHWC f32 map [B][h][w][Csrc], scaled, written into
+ * channels [d0, ...) of an NCHW f32 tensor [B][Cdst][h<<up][w<<up] (msvqgan.py:364-374 + frido.py:654-662). */
+typedef struct FridoPlace { const float* src; float* dst; int32_t B, h, w, Csrc, c0, Cuse, Cdst, d0, up_shift;
+                            float scale; } FridoPlace;
+
 /* step counter update: *step += delta (one thread). */
 typedef struct FridoStepAdd { int32_t* step; int32_t delta; } FridoStepAdd;
 
@@ -208,7 +219,7 @@ typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -218,7 +229,7 @@ typedef struct FridoOp {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill; FridoTimeEmb time_emb;
+        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place;
         char _size[320];
     } u;
 } FridoOp;
@@ -239,6 +250,8 @@ int frido_randn(const FridoRandn* d, frido_stream_t s);
 int frido_step_add(const FridoStepAdd* d, frido_stream_t s);
 int frido_fill(const FridoFill* d, frido_stream_t s);
 int frido_time_emb(const FridoTimeEmb* d, frido_stream_t s);
+int frido_convt(const FridoConvT* d, frido_stream_t s);
+int frido_place(const FridoPlace* d, frido_stream_t s);
 
 /* ---- native executor: run / capture a whole program ---- */
 int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);

@@ -84,6 +84,33 @@ def test_vq_decode_matches_reference_golden():
         assert _rel(dec, g["dec"]) < 2e-4
 
 
+def test_vq_encode_matches_reference_golden():
+    """MSEncoder + coarse-to-fine (quant_conv, VQ, ConvTranspose upsample, shared decoder)."""
+    g = golden("vq_small")
+    m = _vq(VQ_SMALL)
+    enc = m.encode(torch.from_numpy(g["img"]).cuda())
+    assert enc.shape == g["enc"].shape
+    # the coarse scale is quantised on the way to the fine one: allow a VQ code flip to perturb a few pixels
+    err = (enc.cpu() - torch.from_numpy(g["enc"])).abs()
+    scale = float(np.abs(g["enc"]).max())
+    assert float((err > 5e-4 * scale).float().mean()) < 0.02
+    assert float(err[:, :3].max()) < 5e-4 * scale          # coarse channels have no VQ in their path
+    enc2 = m.encode(torch.from_numpy(g["img"]).cuda(), scale=[2.0, 0.5])
+    assert _rel(enc2[:, :3], 2.0 * enc[:, :3].cpu()) < 1e-6 and _rel(enc2[:, 3:], 0.5 * enc[:, 3:].cpu()) < 1e-6
+
+
+def test_vq_encode_three_scales_matches_oracle():
+    from oracle.vqgan import vq_encode
+    from helpers import synth_sd, vq_holder
+    from frido_amd.synth import seeded_normal
+    m = _vq(VQ_SMALL3)
+    x = torch.from_numpy(np.tanh(seeded_normal("enc3:img", (1, 3, 64, 64))))
+    ref = vq_encode(synth_sd(vq_holder(VQ_SMALL3), "first_stage_model."), VQ_SMALL3, x)
+    enc = m.encode(x.cuda())
+    err = (enc.cpu() - ref).abs()
+    assert enc.shape == ref.shape and float((err > 5e-4 * float(ref.abs().max())).float().mean()) < 0.03
+
+
 def test_vq_full_width_decode_matches_reference_golden():
     g = golden("vq_full")
     m = _vq(VQ_FULL)
