@@ -36,6 +36,7 @@ __device__ __forceinline__ void split_bf16(float v, uint32_t& hi, uint32_t& lo) 
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

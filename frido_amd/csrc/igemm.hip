@@ -72,10 +72,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-
-    const frido_bf16* __restrict__ Ab = d.A + (int64_t)z * d.a_bs;
-    const frido_bf16* __restrict__ Bb = d.B + (int64_t)z * d.b_bs;
+    // batch index, optionally two-level (outer x inner, e.g. image x head)
+    int zo = blockIdx.y, zi = 0;
+    if (d.batch_inner > 1) {
+        zo = blockIdx.y / d.batch_inner;
+        zi = blockIdx.y - zo * d.batch_inner;
+    }
+    const frido_bf16* __restrict__ Ab = d.A + (int64_t)zo * d.a_bs + (int64_t)zi * d.a_bs2;
+    const frido_bf16* __restrict__ Bb = d.B + (int64_t)zo * d.b_bs + (int64_t)zi * d.b_bs2;
 
     // ---- LDS-DMA assignments: wave w moves chunks w, w+4, ... ; lane l of a chunk lands at row l>>2, physical
     //      slot l&3, i.e. it must FETCH logical slot (l&3) ^ swz(row) ----
@@ -308,9 +312,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
                 if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
                 if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
-                if (d.residual) v += load_act1(d.residual, (int64_t)z * d.res_bs + (int64_t)m * d.ldr + n, d.res_bf16);
-                if (d.out_f32) store_act1(d.out_f32, (int64_t)z * d.of_bs + (int64_t)m * d.ldo + n, d.out_bf16, v);
-                if (d.out_op) store_op1(d.out_op + (int64_t)z * d.oo_bs, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
+                else if (d.act == FRIDO_ACT_GELU) v = gelu_f(v);
+                if (d.residual) v += load_act1(d.residual, (int64_t)zo * d.res_bs + (int64_t)m * d.ldr + n, d.res_bf16);
+                if (d.out_f32)
+                    store_act1(d.out_f32, (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2 + (int64_t)m * d.ldo + n, d.out_bf16, v);
+                if (d.out_op)
+                    store_op1(d.out_op + (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
             }
         }
     }
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
         if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
         if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
         else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
+        else if (d.act == FRIDO_ACT_GELU) v = gelu_f(v);
         if (d.residual) v += load_act1(d.residual, (int64_t)m * d.ldr + n, d.res_bf16);
         if (d.out_f32) store_act1(d.out_f32, (int64_t)m * d.ldo + n, d.out_bf16, v);
         if (d.out_op) store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
@@ -414,6 +422,7 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
         FRIDO_REQUIRE((d.lda & 7) == 0 && (d.a_bs & 7) == 0, "A rows must be 16-byte aligned");
     }
     if (d.rowvec) FRIDO_REQUIRE(d.rows_per_vec > 0, "rows_per_vec");
+    if (d.batch_inner > 1) FRIDO_REQUIRE(d.batch % d.batch_inner == 0 && !d.residual, "batch must be outer * inner; no residual");
     if (d.geglu) {
         FRIDO_REQUIRE((d.N & 31) == 0 && d.out_op && !d.out_f32 && d.batch == 1 && d.splitk <= 1 && !d.residual && !d.rowvec,
                       "geglu epilogue: N % 32 == 0, operand output only, no split-K / residual / rowvec");

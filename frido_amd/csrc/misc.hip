@@ -287,6 +287,28 @@ __global__ __launch_bounds__(256) void place_kernel(const FridoPlace d) {
     }
 }
 
+__global__ __launch_bounds__(256) void embed_kernel(const FridoEmbed d) {
+    const int D4 = d.D >> 2;
+    const int64_t total = (int64_t)d.rows * D4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / D4;
+        const int c = (int)(i - r * D4) * 4;
+        int64_t tk = d.tokens[r];
+        tk = tk < 0 ? 0 : (tk >= d.vocab ? d.vocab - 1 : tk);
+        const float4 a = *reinterpret_cast<const float4*>(d.tok + tk * d.D + c);
+        const float4 p = *reinterpret_cast<const float4*>(d.pos + (r % d.n) * d.D + c);
+        *reinterpret_cast<float4*>(d.out + r * d.D + c) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void to_u8_kernel(const FridoToU8 d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+        float v = __fmul_rn(__fadd_rn(d.src[i], 1.0f), 127.5f);
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        d.dst[i] = (uint8_t)v;
+    }
+}
+
 __global__ void step_add_kernel(const FridoStepAdd d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *d.step += d.delta;
 }
@@ -366,6 +388,19 @@ extern "C" int frido_place(const FridoPlace* d, frido_stream_t s) {
     hipLaunchKernelGGL(place_kernel, dim3(grid_for(((int64_t)d->B * d->Cuse * d->h * d->w) << (2 * d->up_shift))), dim3(256), 0,
                        (hipStream_t)s, *d);
     return frido_check_launch("place");
+}
+
+extern "C" int frido_embed(const FridoEmbed* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->tokens && d->tok && d->pos && d->out && d->rows > 0 && d->n > 0 && (d->D & 3) == 0 && d->vocab > 0,
+                  "bad arguments");
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((int64_t)d->rows * (d->D >> 2))), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("embed");
+}
+
+extern "C" int frido_to_u8(const FridoToU8* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->src && d->dst && d->n > 0, "bad arguments");
+    hipLaunchKernelGGL(to_u8_kernel, dim3(grid_for(d->n)), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("to_u8");
 }
 
 extern "C" int frido_fill(const FridoFill* d, frido_stream_t s) {

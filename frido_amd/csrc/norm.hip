@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
             const float4 bi = *reinterpret_cast<const float4*>(d.bias + c4 * 4);
             const float y[4] = {(v[i].x - mean) * rstd * w.x + bi.x, (v[i].y - mean) * rstd * w.y + bi.y,
                                 (v[i].z - mean) * rstd * w.z + bi.z, (v[i].w - mean) * rstd * w.w + bi.w};
-            store_op4(d.out_op, d.out_lo, d.nsplit, (int64_t)row * d.C + c4 * 4, y);
+            if (d.out_op) store_op4(d.out_op, d.out_lo, d.nsplit, (int64_t)row * d.C + c4 * 4, y);
+            if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + (int64_t)row * d.C + c4 * 4) = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
 }
@@ -265,7 +266,7 @@ extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
 }
 
 extern "C" int frido_layernorm(const FridoLayerNorm* d, frido_stream_t s) {
-    FRIDO_REQUIRE(d && d->x && d->weight && d->bias && d->out_op, "null pointer");
+    FRIDO_REQUIRE(d && d->x && d->weight && d->bias && (d->out_op || d->out_f32), "null pointer");
     FRIDO_REQUIRE((d->C & 3) == 0 && d->C <= 1024 && d->rows > 0, "C must be a multiple of 4, <= 1024");
     hipLaunchKernelGGL(layernorm_kernel, dim3((d->rows + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("layernorm");

@@ -51,6 +51,8 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_TIME_EMB: return frido_time_emb(&op.u.time_emb, s);
         case FRIDO_OP_CONVT: return frido_convt(&op.u.convt, s);
         case FRIDO_OP_PLACE: return frido_place(&op.u.place, s);
+        case FRIDO_OP_EMBED: return frido_embed(&op.u.embed, s);
+        case FRIDO_OP_TO_U8: return frido_to_u8(&op.u.to_u8, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -224,6 +226,8 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_TIME_EMB: return sizeof(FridoTimeEmb);
         case FRIDO_OP_CONVT: return sizeof(FridoConvT);
         case FRIDO_OP_PLACE: return sizeof(FridoPlace);
+        case FRIDO_OP_EMBED: return sizeof(FridoEmbed);
+        case FRIDO_OP_TO_U8: return sizeof(FridoToU8);
         default: return -1;
     }
 }

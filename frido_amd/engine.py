@@ -194,13 +194,14 @@ class Prog:
     def gemm(self, M, N, K, A, B, *, batch=1, lda=None, ldb=None, a_bs=0, b_bs=0, a_lo=None, b_lo=None,
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
              residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
-             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0):
+             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0):
         """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
         ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
         kw = dict(M=M, N=N, K=K, batch=batch, nsplit=self.nsplit, A=ap, a_lo=alo if a_lo is None else a_lo,
                   a_bs=a_bs, lda=lda if lda is not None else K, B=bp, b_lo=blo if b_lo is None else b_lo,
-                  b_bs=b_bs, ldb=ldb if ldb is not None else K, alpha=alpha, act=act, tile=tile, geglu=geglu)
+                  b_bs=b_bs, ldb=ldb if ldb is not None else K, alpha=alpha, act=act, tile=tile, geglu=geglu, batch_inner=batch_inner, a_bs2=a_bs2, b_bs2=b_bs2,
+                  of_bs2=of_bs2, oo_bs2=oo_bs2)
         if conv:
             kw.update(conv=1, **conv)
         if bias is not None:

@@ -287,3 +287,29 @@ def build_msvqgan_params(root, edconfig, ddconfig, n_embed, embed_dim):
         holder = Nop()
         build_decoder_params(holder, shared_decoder_cfg(embed_dim, i), prefix="d")
         root.shared_decoder.append(holder.d)
+
+
+# ---- cond stage: BERTEmbedder = x-transformers TransformerWrapper(Encoder) (encoders/modules.py:85-97) ------------
+def build_bert_params(root, n_embed, n_layer, vocab_size, max_seq_len, heads=8, dim_head=64):
+    """Parameter tree of frido/modules/x_transformer.py:548-597 (TransformerWrapper) + 370-479 (Encoder)."""
+    tr = Nop()
+    tr.token_emb = Emb(vocab_size, n_embed)
+    pe = Nop()
+    pe.emb = Emb(max_seq_len, n_embed)
+    tr.pos_emb = pe
+    inner = heads * dim_head
+    layers = []
+    for _ in range(n_layer):
+        attn = Nop()
+        attn.to_q, attn.to_k, attn.to_v = Lin(n_embed, inner, False), Lin(n_embed, inner, False), Lin(n_embed, inner, False)
+        attn.to_out = Lin(inner, n_embed)
+        layers.append(nn.ModuleList([Affine(n_embed), attn, Nop()]))
+        ff = Nop()
+        ff.net = seq(seq(Lin(n_embed, 4 * n_embed), Nop()), Nop(), Lin(4 * n_embed, n_embed))
+        layers.append(nn.ModuleList([Affine(n_embed), ff, Nop()]))
+    al = Nop()
+    al.layers = nn.ModuleList(layers)
+    tr.attn_layers = al
+    tr.norm = Affine(n_embed)
+    tr.to_logits = Lin(n_embed, vocab_size)
+    root.transformer = tr

@@ -217,11 +217,12 @@ class VQModelInterface(_Versioned, _Base):
         return self._rt
 
     @torch.no_grad()
-    def decode(self, h_in, force_not_quantize=False, return_code=False, inv_scale=None):
-        """msvqgan.py:376-399.  Returns dec (B,3,H,W) [and per-scale code lists when return_code]."""
+    def decode(self, h_in, force_not_quantize=False, return_code=False, inv_scale=None, to_uint8=False):
+        """msvqgan.py:376-399.  Returns dec (B,3,H,W) [and per-scale code lists when return_code]; to_uint8 returns
+        the (B,H,W,3) uint8 image of scripts/sample_diffusion.py:115-121 straight from the decoder's NHWC output."""
         if not h_in.is_cuda:
             _no_cpu("VQModelInterface.decode", h_in.device)
-        out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code)
+        out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code, to_uint8=to_uint8)
         if return_code:
             dec, idx = out
             return dec, [i.tolist() for i in idx]     # the reference's host lists (msvqgan.py:390)
@@ -234,6 +235,55 @@ class VQModelInterface(_Versioned, _Base):
             _no_cpu("VQModelInterface.encode", x.device)
         assert len(self.channel_range) != 2, "channel_range slicing is not used by any shipped config"
         return self.runtime().encode(x, scale=scale)
+
+
+# ---- cond stage (frido/modules/encoders/modules.py:85-114) ---------------------------------------------
+class BERTEmbedder(_Versioned, nn.Module):
+    """Token ids -> x-transformer encoder embeddings [B, n, n_embed] on the HIP engine."""
+
+    def __init__(self, n_embed, n_layer, vocab_size=30522, max_seq_len=77, device="cuda", use_tokenizer=True,
+                 embedding_dropout=0.0, cond_key="", precision=None):
+        super().__init__()
+        if use_tokenizer:
+            raise NotImplementedError("BERTEmbedder(use_tokenizer=True) needs the HF 'bert-base-uncased' tokenizer files, "
+                                      "which are not reachable offline; every shipped layout2img config sets use_tokenizer: False")
+        self.n_embed, self.n_layer, self.vocab_size, self.max_seq_len = n_embed, n_layer, vocab_size, max_seq_len
+        self.cond_key, self.precision = cond_key, precision
+        holders.build_bert_params(self, n_embed, n_layer, vocab_size, max_seq_len)
+        self._init_versioning()
+        self._plans = {}
+
+    def invalidate(self):
+        self._rt = None
+        self._plans = {}
+
+    @torch.no_grad()
+    def forward(self, text, return_token=False):
+        tokens = text[self.cond_key] if self.cond_key != "" else text
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            _no_cpu("BERTEmbedder", dev)
+        tokens = tokens.to(dev).long()
+        B, n = tokens.shape
+        assert n <= self.max_seq_len
+        from .builder import Builder
+        from .bert_plan import BertPlan
+        from .engine import current_stream_ptr, require_gpu
+        from .runtime import _weights_of
+        if self._rt is None:
+            require_gpu(dev)
+            self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev))
+        key = (B, n)
+        if key not in self._plans:
+            self._plans[key] = BertPlan(self._rt, B=B, n=n, dim=self.n_embed, depth=self.n_layer, vocab=self.vocab_size)
+        plan = self._plans[key]
+        plan.tokens.copy_(tokens.reshape(-1))
+        plan.prog.run(current_stream_ptr(dev))
+        z = plan.out.view(B, n, self.n_embed).clone()
+        return (z, tokens) if return_token else z
+
+    def encode(self, text):
+        return self(text)
 
 
 # ---- EMA shadow (frido/modules/ema.py) ---------------------------------------------------------------
@@ -416,7 +466,7 @@ class FridoDiffusion(_Base):
         return out[0] if isinstance(out, tuple) and not return_ids else out
 
     @torch.no_grad()
-    def decode_first_stage(self, z_in, predict_cids=False, force_not_quantize=False, return_code=False):
+    def decode_first_stage(self, z_in, predict_cids=False, force_not_quantize=False, return_code=False, to_uint8=False):
         """frido.py:823-891: per-scale 1/scale_factor (fused into the VQ kernel) + first-stage decode."""
         assert not predict_cids
         embed = self.first_stage_model.embed_dim
@@ -426,7 +476,7 @@ class FridoDiffusion(_Base):
         else:
             sfs = self.scale_factor.detach().float().cpu().numpy()
             inv = [float(np.float32(1.0) / np.float32(v)) for v in sfs]
-        return self.first_stage_model.decode(z_in, return_code=return_code, inv_scale=inv)
+        return self.first_stage_model.decode(z_in, return_code=return_code, inv_scale=inv, to_uint8=to_uint8)
 
     @torch.no_grad()
     def encode_first_stage(self, x):

@@ -300,8 +300,10 @@ class DecoderRuntime:
         self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
         self.plans = {}
 
-    def decode(self, z, inv_scale=None, return_code=False):
-        """z (B, Ctot, h, w) NCHW latent -> image (B, 3, H, W); inv_scale: per-scale multiplier (1/scale_factor)."""
+    def decode(self, z, inv_scale=None, return_code=False, to_uint8=False):
+        """z (B, Ctot, h, w) NCHW latent -> image (B, 3, H, W); inv_scale: per-scale multiplier (1/scale_factor).
+        to_uint8: return the (B, H, W, 3) uint8 array of scripts/sample_diffusion.py:115-121 instead (4x smaller to
+        gather / write)."""
         B, Ct, h, w = z.shape
         embed = self.cfg["embed_dim"]
         inv = tuple(float(v) for v in (inv_scale if inv_scale is not None else [1.0] * len(embed)))
@@ -316,6 +318,10 @@ class DecoderRuntime:
         _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=zc.data_ptr(), dst=z_state.data_ptr(), B=B, HW=h * w, Csrc=Ct, c0=0,
               Cuse=Ct, Cdst=Ct, d0=0, to_nchw=0)
         plan.prog.run(st)
+        if to_uint8:
+            u8 = torch.empty(B, plan.H, plan.W, plan.a.out_ch, dtype=torch.uint8, device=self.device)
+            _run1(self.b, "FRIDO_OP_TO_U8", st, src=plan.out_nhwc.data_ptr(), dst=u8.data_ptr(), n=u8.numel())
+            return (u8, [i.view(B, -1) for i in plan.idx]) if return_code else u8
         out = torch.empty(B, plan.a.out_ch, plan.H, plan.W, dtype=torch.float32, device=self.device)
         _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=plan.out_nhwc.data_ptr(), dst=out.data_ptr(), B=B, HW=plan.H * plan.W,
               Csrc=plan.a.out_ch, c0=0, Cuse=plan.a.out_ch, Cdst=plan.a.out_ch, d0=0, to_nchw=1)

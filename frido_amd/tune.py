@@ -15,7 +15,7 @@ ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
 
 _SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
                "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
-               "res_bs", "res_bf16", "out_bf16")
+               "res_bs", "res_bf16", "out_bf16", "batch_inner", "a_bs2", "b_bs2", "of_bs2", "oo_bs2")
 
 
 def _buf(name, nbytes, device):
@@ -59,16 +59,16 @@ def best_tile(st, device, stream):
     if st.conv:
         a_elems = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin
     else:
-        a_elems = st.batch * max(st.a_bs, st.M * st.lda) if st.a_bs else st.M * st.lda
-    b_elems = st.batch * st.b_bs if st.b_bs else st.N * st.ldb
+        a_elems = st.batch * max(st.a_bs, st.a_bs2, st.M * st.lda) if (st.a_bs or st.a_bs2) else st.M * st.lda
+    b_elems = st.batch * max(st.b_bs, st.b_bs2, st.N * st.ldb) if (st.b_bs or st.b_bs2) else st.N * st.ldb
     a_elems, b_elems = (a_elems + 7) // 8 * 8, (b_elems + 7) // 8 * 8
     t.A, t.a_lo = _buf("A", a_elems * 2 * ns, device), a_elems
     t.B, t.b_lo = _buf("B", b_elems * 2 * ns, device), b_elems
     rows = st.M * st.batch
     if st.out_f32:
-        t.out_f32 = _buf("O", max(st.of_bs * st.batch, st.M * st.ldo) * 4, device)
+        t.out_f32 = _buf("O", max(max(st.of_bs, st.of_bs2) * st.batch, st.M * st.ldo) * 4 + 4096, device)
     if st.out_op:
-        n = max(st.oo_bs * st.batch, st.M * st.ldoo)
+        n = max(max(st.oo_bs, st.oo_bs2) * st.batch, st.M * st.ldoo) + 4096
         n = (n + 7) // 8 * 8
         t.out_op, t.oo_lo = _buf("OO", n * 2 * ns, device), n
     if st.residual:

@@ -31,7 +31,7 @@ typedef uint16_t frido_bf16;
 #define FRIDO_EHIP (-2)
 #define FRIDO_EUNSUPPORTED (-3)
 
-enum { FRIDO_ACT_NONE = 0, FRIDO_ACT_RELU = 1, FRIDO_ACT_SILU = 2 };
+enum { FRIDO_ACT_NONE = 0, FRIDO_ACT_RELU = 1, FRIDO_ACT_SILU = 2, FRIDO_ACT_GELU = 3 /* exact erf GELU */ };
 
 /* ------------------------------------------------------------------------------------------
  * frido_gemm — implicit-GEMM on the MFMA pipe:  for z < batch:
@@ -72,6 +72,9 @@ typedef struct FridoGemm {
     float* out_f32; int64_t of_bs; int32_t ldo;
     int32_t res_bf16, out_bf16; /* 1: `residual` / `out_f32` point at bf16 activations (bf16 residual stream) */
     frido_bf16* out_op; int64_t oo_lo; int64_t oo_bs; int32_t ldoo;
+    int32_t batch_inner;        /* > 1: blockIdx.y = zo * batch_inner + zi (e.g. batch x heads); the *_bs strides apply
+                                   to zo and the *_bs2 strides to zi */
+    int64_t a_bs2, b_bs2, of_bs2, oo_bs2;
     int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to `ws` [splitk][M][N] f32 and a
                                    second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
     float* ws;
@@ -116,6 +119,7 @@ typedef struct FridoLayerNorm {
     const float* weight; const float* bias;
     int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
     int32_t x_bf16;
+    float* out_f32;             /* optional f32 copy of the result (final norm of the cond-stage encoder) */
 } FridoLayerNorm;
 
 /* Row softmax (attention.py:188, taming model.py:181): x[rows][N] f32 (ld) -> operand [rows][Npad]
@@ -210,6 +214,15 @@ typedef struct FridoConvT { const float* src; float* dst; const float* weight; c
 typedef struct FridoPlace { const float* src; float* dst; int32_t B, h, w, Csrc, c0, Cuse, Cdst, d0, up_shift;
                             float scale; } FridoPlace;
 
+/* Token + absolute position embedding (frido/modules/x_transformer.py:25-36,620-622):
+ * out[r][:] = tok[tokens[r]][:] + pos[r % n][:]   (f32, D % 4 == 0). */
+typedef struct FridoEmbed { const int64_t* tokens; const float* tok; const float* pos; float* out;
+                            int32_t rows, n, D, vocab; } FridoEmbed;
+
+/* Output conversion of scripts/sample_diffusion.py:115-121 (custom_to_np): NHWC f32 in [-1, 1] -> uint8 NHWC,
+ * ((x + 1) * 127.5) clamped to [0, 255] and truncated. */
+typedef struct FridoToU8 { const float* src; uint8_t* dst; int64_t n; } FridoToU8;
+
 /* step counter update: *step += delta (one thread). */
 typedef struct FridoStepAdd { int32_t* step; int32_t delta; } FridoStepAdd;
 
@@ -219,7 +232,7 @@ typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -229,8 +242,8 @@ typedef struct FridoOp {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place;
-        char _size[320];
+        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8;
+        char _size[384];
     } u;
 } FridoOp;
 
@@ -252,6 +265,8 @@ int frido_fill(const FridoFill* d, frido_stream_t s);
 int frido_time_emb(const FridoTimeEmb* d, frido_stream_t s);
 int frido_convt(const FridoConvT* d, frido_stream_t s);
 int frido_place(const FridoPlace* d, frido_stream_t s);
+int frido_embed(const FridoEmbed* d, frido_stream_t s);
+int frido_to_u8(const FridoToU8* d, frido_stream_t s);
 
 /* ---- native executor: run / capture a whole program ---- */
 int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);

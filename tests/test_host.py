@@ -112,3 +112,34 @@ def test_product_never_imports_the_oracle():
 def test_full_width_holder_has_reference_parameter_count():
     from helpers import unet_holder
     assert sum(p.numel() for p in unet_holder(UNET_FULL).parameters()) == int(golden("unet_full")["nparam"]) == 511669446   # the reference module (SURVEY App. A rounds to 511.67 M)
+
+
+def test_checkpoint_ingestion_roundtrip(tmp_path):
+    """A reference-style checkpoint ({'state_dict': ...} with model.*, model_ema.*, first_stage_model.*, cond_stage_model.*,
+    scale_factor) loads through init_from_ckpt / load_state_dict(strict=False) (scripts/sample_diffusion.py:452-469)."""
+    from frido_amd.models import instantiate_from_config
+    from frido_amd.synth import fill_module
+    cfg = frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    src = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    fill_module(src.model, "model.")
+    fill_module(src.first_stage_model, "first_stage_model.")
+    fill_module(src.cond_stage_model, "cond_stage_model.")
+    src.model_ema.copy_to  # noqa: B018  (exists)
+    for k, v in src.model_ema.named_buffers():
+        if v.dtype.is_floating_point and v.dim() > 0:
+            v.mul_(0).add_(0.5)
+    src.scale_factor.copy_(torch.tensor([0.7, 1.3]))
+    path = tmp_path / "model.ckpt"
+    sd = dict(src.state_dict())
+    sd["some.unknown.key"] = torch.zeros(1)               # strict=False tolerates extras
+    torch.save({"state_dict": sd, "global_step": 1}, path)
+    cfg2 = frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    cfg2["ckpt_path"] = str(path)
+    dst = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg2))
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    w0 = dst.model.diffusion_model.time_embed[0].weight.clone()
+    with dst.ema_scope():                                  # EMA weights swapped in (frido.py:181-194) ...
+        assert float(dst.model.diffusion_model.time_embed[0].weight.mean()) == 0.5
+    assert torch.equal(dst.model.diffusion_model.time_embed[0].weight, w0)    # ... and restored
+    assert torch.equal(dst.scale_factor, torch.tensor([0.7, 1.3]))

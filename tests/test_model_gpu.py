@@ -111,6 +111,17 @@ def test_vq_encode_three_scales_matches_oracle():
     assert enc.shape == ref.shape and float((err > 5e-4 * float(ref.abs().max())).float().mean()) < 0.03
 
 
+def test_uint8_output_path():
+    """scripts/sample_diffusion.py:115-121 custom_to_np, fused after the decoder."""
+    g = golden("vq_small")
+    m = _vq(VQ_SMALL)
+    h = torch.from_numpy(g["h"]).cuda()
+    f = m.decode(h)
+    u8 = m.decode(h, to_uint8=True)
+    ref = ((f + 1) * 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert u8.dtype == torch.uint8 and u8.shape == ref.shape and torch.equal(u8, ref)
+
+
 def test_vq_full_width_decode_matches_reference_golden():
     g = golden("vq_full")
     m = _vq(VQ_FULL)
@@ -124,18 +135,6 @@ def test_vq_full_width_decode_matches_reference_golden():
         assert abs(float(dec.double().sum()) - float(g["dec_sum"])) < 2e-4 * float(g["dec_abs_sum"])
 
 
-def _frido(ucfg, vcfg):
-    from frido_amd.models import instantiate_from_config
-    cfg = frido_cfg(ucfg, vcfg, BERT_SMALL)
-    cfg["cond_stage_config"] = "__is_unconditional__"   # conditioning tensors come from the golden (cond stage = SURVEY §8f)
-    cfg["conditioning_key"] = "crossattn"
-    m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
-    fill_module(m.model, "model.")
-    fill_module(m.first_stage_model, "first_stage_model.")
-    m.scale_factor.copy_(torch.tensor([0.9, 1.1, 1.05][:len(vcfg["embed_dim"])]))
-    return m.cuda().eval()
-
-
 class _Tape:
     def __init__(self, flat):
         self.t, self.pos = torch.from_numpy(np.asarray(flat, dtype=np.float32)), 0
@@ -146,6 +145,67 @@ class _Tape:
         assert out.numel() == n
         self.pos += n
         return out
+
+
+def test_bert_embedder_matches_reference_golden():
+    """the cond stage (BERTEmbedder -> x-transformer encoder) on the HIP path."""
+    from frido.modules.encoders.modules import BERTEmbedder
+    for name in ("sampler_small", "sampler_small3"):
+        g = golden(name)
+        m = fill_module(BERTEmbedder(**BERT_SMALL), "cond_stage_model.").cuda()
+        c = m.encode(torch.from_numpy(g["tokens"]).cuda())
+        assert c.shape == g["c"].shape and _rel(c, g["c"]) < 1e-4
+
+
+def test_bert_embedder_full_size_matches_oracle():
+    from frido.modules.encoders.modules import BERTEmbedder
+    from frido_amd.configs import BERT_FULL
+    from frido_amd.synth import fill_tensor
+    from oracle.bert import bert_embed
+    cfg = dict(BERT_FULL, vocab_size=1024 + 256)
+    m = fill_module(BERTEmbedder(**cfg), "cond_stage_model.").cuda()
+    tokens = torch.from_numpy(np.random.default_rng(3).integers(0, 1024, (4, 26)))
+    sd = {"cond_stage_model." + k: torch.from_numpy(fill_tensor("cond_stage_model." + k, v.shape)) for k, v in m.state_dict().items()}
+    ref = bert_embed(sd, tokens, cfg["n_layer"])
+    assert _rel(m(tokens.cuda()), ref) < 3e-4
+
+
+def test_full_pipeline_with_cond_stage_and_get_input():
+    """get_input -> encode + conditioning, sample, decode through the reference's FridoDiffusion API."""
+    from frido_amd.models import instantiate_from_config
+    from frido.models.diffusion.ddim import DDIMSampler
+    g = golden("sampler_small")
+    cfg = frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    fill_module(m.model, "model.")
+    fill_module(m.first_stage_model, "first_stage_model.")
+    fill_module(m.cond_stage_model, "cond_stage_model.")
+    m.scale_factor.copy_(torch.tensor([0.9, 1.1]))
+    m = m.cuda().eval()
+    c = m.get_learned_conditioning(torch.from_numpy(g["tokens"]).cuda())
+    assert _rel(c, g["c"]) < 1e-4
+    batch = {"image": torch.tanh(torch.randn(2, 64, 64, 3)), "objects_bbox": torch.from_numpy(g["tokens"])}
+    z, cc, x, xrec = m.get_input(batch, "image", return_first_stage_outputs=True, force_c_encode=True)
+    assert z.shape == (2, 6, 16, 16) and cc.shape == c.shape and xrec.shape == (2, 3, 64, 64)
+    assert _rel(cc, g["c"]) < 1e-4
+    tape = _Tape(g["ddim_eta1_noise"])
+    with m.ema_scope():
+        pass
+    samples, _ = DDIMSampler(m).sample(S=4, batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=1.0, verbose=False,
+                                       log_every_t=2, noise=tape)
+    assert _rel(samples, g["ddim_eta1_samples"]) < 1e-3
+
+
+def _frido(ucfg, vcfg):
+    from frido_amd.models import instantiate_from_config
+    cfg = frido_cfg(ucfg, vcfg, BERT_SMALL)
+    cfg["cond_stage_config"] = "__is_unconditional__"   # conditioning tensors come from the golden (cond stage = SURVEY §8f)
+    cfg["conditioning_key"] = "crossattn"
+    m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    fill_module(m.model, "model.")
+    fill_module(m.first_stage_model, "first_stage_model.")
+    m.scale_factor.copy_(torch.tensor([0.9, 1.1, 1.05][:len(vcfg["embed_dim"])]))
+    return m.cuda().eval()
 
 
 @pytest.mark.parametrize("name,ucfg,vcfg", [("sampler_small", UNET_SMALL, VQ_SMALL), ("sampler_small3", UNET_SMALL3, VQ_SMALL3)])

@@ -108,3 +108,16 @@ def test_sampler_oracle_bit_exact(name, ucfg, vcfg):
     e = torch.cat((torch.zeros(e.size(0), start, 16, 16), e), dim=1)
     xp, px0 = S._x_prev(x, e, al[30], alp[30], sig[30], np.sqrt(1.0 - al)[30], start, torch.from_numpy(g["step_noise"]))
     assert torch.equal(xp, torch.from_numpy(g["step_xprev"])) and torch.equal(px0, torch.from_numpy(g["step_predx0"]))
+
+
+def test_bert_oracle_bit_exact():
+    """Cond stage (BERTEmbedder): oracle vs the `c` tensors the reference produced from the same token ids."""
+    from golden_cfg import BERT_SMALL
+    from frido_amd.models import BERTEmbedder
+    from oracle.bert import bert_embed
+    m = BERTEmbedder(**BERT_SMALL)
+    sd = synth_sd(m, "cond_stage_model.")
+    for name in ("sampler_small", "sampler_small3"):
+        g = golden(name)
+        c = bert_embed(sd, torch.from_numpy(g["tokens"]), BERT_SMALL["n_layer"])
+        assert torch.equal(c, torch.from_numpy(g["c"]))
