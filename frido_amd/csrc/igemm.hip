@@ -38,19 +38,23 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int BK>
 struct Geo {
-    static constexpr int D = NS == 1 ? 4 : 3;               // LDS ring depth
-    static constexpr int JA = BM / 64, JB = BN / 64;        // 1-KiB chunks per wave per plane
+    static constexpr int ROWB = BK * 2;                     // bytes per LDS row
+    static constexpr int CHR = 1024 / ROWB;                 // rows per 1-KiB LDS-DMA chunk (16 / 8)
+    static constexpr int JA = BM / (4 * CHR), JB = BN / (4 * CHR);   // chunks per wave per plane
     static constexpr int LPT = (JA + JB) * NS;              // LDS-DMA instructions per thread per k-tile
-    static constexpr int PLANE = (BM + BN) * 64;
+    static constexpr int PLANE = (BM + BN) * ROWB;
     static constexpr int STAGE = NS * PLANE;
+    static constexpr int D = (4 * STAGE <= 98304 && NS == 1) ? 4 : 3;   // LDS ring depth
     static constexpr int SMEM = D * STAGE;
+    static_assert(SMEM <= 163840, "LDS budget");
 };
 
-template <int BM, int BN, int NS, bool CONV>
+template <int BM, int BN, int NS, bool CONV, int BK>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
-    using G = Geo<BM, BN, NS>;
+    using G = Geo<BM, BN, NS, BK>;
+    constexpr int ROWB = G::ROWB, CHR = G::CHR, KS = BK / 32;
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int D = G::D, JA = G::JA, JB = G::JB, PLANE = G::PLANE, STAGE = G::STAGE;
@@ -83,8 +87,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
 
     // ---- LDS-DMA assignments: wave w moves chunks w, w+4, ... ; lane l of a chunk lands at row l>>2, physical
     //      slot l&3, i.e. it must FETCH logical slot (l&3) ^ swz(row) ----
-    const int lrow = lane >> 2;
-    const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
+    // BK = 32: 64-B rows, 4 slots, slot q of row r at q ^ ((4 - (r>>2)) & 3);  BK = 64: 128-B rows, 8 slots, q ^ ((r>>1) & 7)
+    const int lrow = BK == 32 ? lane >> 2 : lane >> 3;
+    const int lq = BK == 32 ? (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3)
+                            : (lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7);
     // conv: element offset of tap (0,0) of this row's receptive field + a bit mask of the taps that fall inside
     // the (logical) input; with resampling folded in (up/dn shifts) the per-tap offsets are tabulated instead
     int64_t a_off[JA];
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     int a_b[JA], a_oy[JA], a_ox[JA];
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-        const int row = (wave + 4 * j) * 16 + lrow;
+        const int row = (wave + 4 * j) * CHR + lrow;
         int m = m0 + row;
         if (CONV) {
             const bool okm = m < d.M;
@@ -118,14 +124,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     int64_t b_off[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        const int row = (wave + 4 * j) * 16 + lrow;
+        const int row = (wave + 4 * j) * CHR + lrow;
         int n = n0 + row;
         n = n < d.N ? n : d.N - 1;
         b_off[j] = (int64_t)n * d.ldb + lq * 8;
     }
 
     // k-tile range of this workgroup (split-K: gridDim.z slices)
-    const int nk_all = d.K >> 5;
+    const int nk_all = d.K / BK;
     const int kz = blockIdx.z;
     const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kt0 = kz * per;
@@ -134,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     int kc = 0, ky = 0, kx = 0, tap = 0;   // conv k-walk (uniform): channel offset inside the tap, tap coordinates
     int64_t tap_off = 0;                   // ((ky * Ws + kx) * Cin + kc): offset of the current k-tile from tap (0,0)
     if (CONV && kt0) {
-        const int cpt = cin >> 5;
+        const int cpt = cin / BK;
         tap = kt0 / cpt;
-        kc = (kt0 - tap * cpt) << 5;
+        kc = (kt0 - tap * cpt) * BK;
         ky = tap / kw;
         kx = tap - ky * kw;
         tap_off = ((int64_t)ky * ws + kx) * cin + kc;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * 4096), 16, 0, 0);
                 }
             } else {
-                const int64_t off = a_off[j] + (int64_t)kt * 32;
+                const int64_t off = a_off[j] + (int64_t)kt * BK;
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     src = Ab + (p ? a_lo : 0) + off;
@@ -177,15 +183,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            const int64_t off = b_off[j] + (int64_t)kt * 32;
+            const int64_t off = b_off[j] + (int64_t)kt * BK;
 #pragma unroll
             for (int p = 0; p < NS; ++p)
                 __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (p ? b_lo : 0) + off),
-                                                 (lptr_t)(sb + p * PLANE + BM * 64 + j * 4096), 16, 0, 0);
+                                                 (lptr_t)(sb + p * PLANE + BM * ROWB + j * 4096), 16, 0, 0);
         }
         if (CONV) {   // advance the (tap, channel) walk
-            kc += 32;
-            tap_off += 32;
+            kc += BK;
+            tap_off += BK;
             if (kc == cin) {
                 kc = 0;
                 ++tap;
@@ -203,10 +209,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
 
     // fragment addresses: row (lane & 15) of a 16-row MFMA tile, logical slot (lane >> 4)
     const int frow = lane & 15;
-    const int fslot = ((lane >> 4) ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4;
+    const int fslot0 = BK == 32 ? ((lane >> 4) ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4 : ((lane >> 4) ^ (frow >> 1)) << 4;
+    const int fslot1 = ((4 + (lane >> 4)) ^ (frow >> 1)) << 4;          // second k-step of a BK = 64 row
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * 64 + fslot;
-    const unsigned b_frag = lds0 + BM * 64 + (wn * (BN / WN) + frow) * 64 + fslot;
+    const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * ROWB;
+    const unsigned b_frag = lds0 + BM * ROWB + (wn * (BN / WN) + frow) * ROWB;
 
     // ---- prologue: fill D-1 stages ----
 #pragma unroll
@@ -224,34 +231,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
             nb_ = nb_ >= D ? nb_ - D : nb_;
             issue(kt0 + kt + D - 1, nb_);
         }
-        const unsigned sa = a_frag + buf * STAGE, sbb = b_frag + buf * STAGE;
-        bf16x8 fa[NS][TM];
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
+        for (int ks = 0; ks < KS; ++ks) {
+            const int fs = ks ? fslot1 : fslot0;
+            const unsigned sa = a_frag + buf * STAGE + fs, sbb = b_frag + buf * STAGE + fs;
+            bf16x8 fa[NS][TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[p][i] = lds_read128(sa + p * PLANE + i * 1024);
-        bf16x8 fb[2][NS];
+            for (int p = 0; p < NS; ++p)
 #pragma unroll
-        for (int p = 0; p < NS; ++p) fb[0][p] = lds_read128(sbb + p * PLANE);
+                for (int i = 0; i < TM; ++i) fa[p][i] = lds_read128(sa + p * PLANE + i * 16 * ROWB);
+            bf16x8 fb[2][NS];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (j + 1 < TN) {
+            for (int p = 0; p < NS; ++p) fb[0][p] = lds_read128(sbb + p * PLANE);
 #pragma unroll
-                for (int p = 0; p < NS; ++p) fb[(j + 1) & 1][p] = lds_read128(sbb + p * PLANE + (j + 1) * 1024);
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS) : "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < TN; ++j) {
+                if (j + 1 < TN) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (NS == 2) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][1], acc[i][j], 0, 0, 0);
+                    for (int p = 0; p < NS; ++p) fb[(j + 1) & 1][p] = lds_read128(sbb + p * PLANE + (j + 1) * 16 * ROWB);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (NS == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][1], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         buf = buf + 1 == D ? 0 : buf + 1;
     }
@@ -343,10 +354,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
     }
 }
 
-template <int BM, int BN, int NS, bool CONV>
+template <int BM, int BN, int NS, bool CONV, int BK>
 int set_attr() {
-    constexpr int smem = Geo<BM, BN, NS>::SMEM;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV>),
+    constexpr int smem = Geo<BM, BN, NS, BK>::SMEM;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV, BK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         frido_set_error("igemm: cannot set dynamic LDS size %d", smem);
         return FRIDO_EHIP;
@@ -354,12 +365,12 @@ int set_attr() {
     return FRIDO_OK;
 }
 
-template <int BM, int BN, int NS, bool CONV>
+template <int BM, int BN, int NS, bool CONV, int BK>
 int launch(const FridoGemm& d, hipStream_t s) {
-    constexpr int smem = Geo<BM, BN, NS>::SMEM;
+    constexpr int smem = Geo<BM, BN, NS, BK>::SMEM;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const int sk = d.splitk > 1 ? d.splitk : 1;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV>), dim3(tiles, d.batch, sk), dim3(256), smem, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK>), dim3(tiles, d.batch, sk), dim3(256), smem, s, d);
     if (sk > 1) {
         const int64_t total = (int64_t)d.M * d.N;
         const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
@@ -371,13 +382,26 @@ int launch(const FridoGemm& d, hipStream_t s) {
 template <int NS, bool CONV>
 int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
     switch (tile) {
-        case 1: return launch<128, 128, NS, CONV>(d, s);
-        case 2: return launch<128, 192, NS, CONV>(d, s);
-        case 4: return launch<128, 64, NS, CONV>(d, s);
-        case 5: return launch<64, 192, NS, CONV>(d, s);
-        case 6: return launch<64, 128, NS, CONV>(d, s);
-        default: return launch<64, 64, NS, CONV>(d, s);
+        case 1: return launch<128, 128, NS, CONV, 32>(d, s);
+        case 2: return launch<128, 192, NS, CONV, 32>(d, s);
+        case 4: return launch<128, 64, NS, CONV, 32>(d, s);
+        case 5: return launch<64, 192, NS, CONV, 32>(d, s);
+        case 6: return launch<64, 128, NS, CONV, 32>(d, s);
+        default: break;
     }
+    if constexpr (NS == 1) {      // BK = 64 variants (bf16 mode only: the bf16x3 planes would not fit the LDS budget)
+        const bool k64 = (d.K & 63) == 0 && (!CONV || (d.Cin & 63) == 0);
+        if (k64) switch (tile) {
+            case 11: return launch<128, 128, NS, CONV, 64>(d, s);
+            case 12: return launch<128, 192, NS, CONV, 64>(d, s);
+            case 13: return launch<64, 64, NS, CONV, 64>(d, s);
+            case 14: return launch<128, 64, NS, CONV, 64>(d, s);
+            case 15: return launch<64, 192, NS, CONV, 64>(d, s);
+            case 16: return launch<64, 128, NS, CONV, 64>(d, s);
+            default: break;
+        }
+    }
+    return launch<64, 64, NS, CONV, 32>(d, s);
 }
 
 int pick_tile(const FridoGemm& d) {
@@ -396,7 +420,8 @@ int pick_tile(const FridoGemm& d) {
 int frido_igemm_init() {
     int rc = 0;
 #define FRIDO_SET_ALL(BM, BN) \
-    rc |= set_attr<BM, BN, 1, true>() | set_attr<BM, BN, 1, false>() | set_attr<BM, BN, 2, true>() | set_attr<BM, BN, 2, false>()
+    rc |= set_attr<BM, BN, 1, true, 32>() | set_attr<BM, BN, 1, false, 32>() | set_attr<BM, BN, 2, true, 32>() | \
+          set_attr<BM, BN, 2, false, 32>() | set_attr<BM, BN, 1, true, 64>() | set_attr<BM, BN, 1, false, 64>()
     FRIDO_SET_ALL(128, 128); FRIDO_SET_ALL(128, 192); FRIDO_SET_ALL(64, 64);
     FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
 #undef FRIDO_SET_ALL
@@ -429,7 +454,7 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     }
     if (d.splitk > 1) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
-        FRIDO_REQUIRE(d.splitk <= (d.K >> 5), "more K slices than k-tiles");
+        FRIDO_REQUIRE(d.splitk <= (d.K >> 6), "more K slices than k-tiles");
     }
     const int tile = d.tile ? d.tile : pick_tile(d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

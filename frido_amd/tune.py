@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 TILES = (1, 2, 3, 4, 5, 6)          # see include/frido_hip.h FridoGemm.tile
+TILES64 = (11, 12, 13, 14, 15, 16)  # BK = 64 variants
 _cache = {}
 _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
@@ -83,18 +84,21 @@ def best_tile(st, device, stream):
             t.rows_per_vec = 1 << 30
     L = _lib.lib()
     kind = _lib.OP_KINDS["FRIDO_OP_GEMM"]
-    reps = 3
+    reps = 5
     best, best_t = (0, 1), float("inf")
     nk = st.K // 32
     small = st.batch == 1 and st.M * st.N <= (1 << 23) and not st.geglu       # split-K only pays for small outputs with a long K
-    splits = [1] + [k for k in (2, 4, 8) if small and nk >= 4 * k]
+    splits = [1] + [k for k in (2, 4, 8) if small and nk >= 8 * k]
     for sk in splits:
         t.splitk = sk
         t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None
-        for tile in TILES:
-            if tile in (1, 2, 4) and st.M < 64:
+        # BK = 64 halves the barrier count but costs a ring stage of occupancy: it only wins on small-M shapes
+        k64 = (st.nsplit == 1 and st.K % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
+               and st.M * st.batch <= 4096)
+        for tile in TILES + (TILES64 if k64 else ()):
+            if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue
-            if sk > 1 and tile in (1, 2):
+            if sk > 1 and tile % 10 in (1, 2):
                 continue
             t.tile = tile
             arr = _lib.pack_ops([(kind, t)] * (reps + 1))
@@ -102,7 +106,7 @@ def best_tile(st, device, stream):
             rc = L.frido_run_timed(C.addressof(arr), reps + 1, stream, ms)
             if rc != 0:
                 continue
-            dt = min(list(ms)[1:])
+            dt = sorted(list(ms)[1:])[reps // 2]
             if dt < best_t:
                 best, best_t = (tile, sk), dt
     _cache[sig] = best

@@ -78,7 +78,8 @@ typedef struct FridoGemm {
     int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to `ws` [splitk][M][N] f32 and a
                                    second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
     float* ws;
-    int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 */
+    int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 (BK 32);
+                                   11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64) */
 } FridoGemm;
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two

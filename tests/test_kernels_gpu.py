@@ -114,6 +114,32 @@ def test_gemm_split_k_is_deterministic_and_correct(nsplit, conv, splitk, tile):
     assert torch.equal(first, out.view())        # fixed-order reduction: bit-reproducible
 
 
+@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("conv", [False, True])
+def test_gemm_bk64_variants(tile, conv):
+    from frido_amd.builder import ACT_SILU
+    if conv:
+        B, H, W, Cin, Cout = 2, 12, 10, 128, 200
+        x, w, bias = _t("qx", B, Cin, H, W), _t("qw", Cout, Cin, 3, 3) / np.sqrt(9 * Cin), _t("qb", Cout)
+        ref = F.silu(F.conv2d(x, w, bias, padding=1)).permute(0, 2, 3, 1).reshape(-1, Cout)
+        b = _builder(1, {"c.weight": w.cuda(), "c.bias": bias.cuda()})
+        xd = x.cuda()
+        a = b.pack(xd.data_ptr(), B, H * W, Cin, 0, Cin, nchw=True)
+        out = b.conv(a, B, H, W, "c", act=ACT_SILU)
+    else:
+        M, N, K = 300, 200, 64 * 5
+        a_, w, bias = _t("qa", M, K), _t("qw2", N, K) / np.sqrt(K), _t("qb2", N)
+        ref = F.silu(a_ @ w.t() + bias)
+        b = _builder(1, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+        ad = a_.cuda()
+        a = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+        out = b.linear(a, "w", act=ACT_SILU)
+    st = b.prog.ops[-1][1]
+    st.tile, st.splitk = tile, 1
+    _run(b)
+    assert _relerr(out.to_f32().cpu(), ref) < 2e-2
+
+
 CONV_CASES = [
     # Cin, Cout, H, W, k, stride, pad, up, dn, asym
     (32, 64, 16, 16, 3, 1, 1, 0, 0, False),

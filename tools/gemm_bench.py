@@ -13,6 +13,7 @@ from frido_amd.builder import Builder  # noqa: E402
 from frido_amd.engine import require_gpu  # noqa: E402
 
 NAMES = {1: "128x128", 2: "128x192", 3: "64x64", 4: "128x64", 5: "64x192", 6: "64x128"}
+NAMES.update({k + 10: v + "k64" for k, v in list(NAMES.items())})
 
 
 def main():
@@ -40,7 +41,7 @@ def main():
         xo = b.pack(x.data_ptr(), 1, M, K, 0, K)
         b.linear(xo, "w")
         flops = 2.0 * M * N * K
-    tiles = [int(t) for t in rest[1].split(",")] if len(rest) > 1 else [1, 2, 3, 4, 5, 6]
+    tiles = [int(t) for t in rest[1].split(",")] if len(rest) > 1 else [1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16]
     sp = torch.cuda.current_stream().cuda_stream
     b.prog.run(sp)
     kind, st = b.prog.ops[-1]
@@ -51,7 +52,7 @@ def main():
         ms = (C.c_float * reps)()
         _lib.check(_lib.lib().frido_run_timed(C.addressof(arr), reps, sp, ms), "run")
         t = sorted(ms)[reps // 2]
-        print(f"tile {NAMES[tile]:8s} {t * 1e3:8.1f} us  {flops / t / 1e9:8.1f} TF/s")
+        print(f"tile {NAMES[tile]:12s} {t * 1e3:8.1f} us  {flops / t / 1e9:8.1f} TF/s")
 
 
 if __name__ == "__main__":
