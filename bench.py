@@ -51,9 +51,15 @@ def gemm_roofline(eng, stream_ptr, precision):
     k_gemm = _lib.OP_KINDS["FRIDO_OP_GEMM"]
     t_gemm = flops = n_gemm = 0
     conv_t = conv_f = 0.0
+    alg_bytes = 0.0
     for (kind, st), t in zip(prog.ops, ms):
         if kind == k_gemm:
             f = 2.0 * st.M * st.N * st.K * st.batch
+            esz = 2 * st.nsplit
+            a_b = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin * esz if st.conv else st.M * st.K * esz * st.batch
+            o_b = st.M * (st.N // 2 if st.geglu else st.N) * st.batch * ((2 if st.out_bf16 else 4) * bool(st.out_f32) + esz * bool(st.out_op))
+            r_b = st.M * st.N * (2 if st.res_bf16 else 4) if st.residual else 0
+            alg_bytes += a_b + st.N * st.K * esz * (1 if not st.b_bs else st.batch) + o_b + r_b
             t_gemm += t
             flops += f
             n_gemm += 1
@@ -63,8 +69,14 @@ def gemm_roofline(eng, stream_ptr, precision):
     total = sum(ms)
     achieved = flops / (t_gemm * 1e-3) / 1e12
     peak = 2500.0
+    traffic, traffic_src = None, None
+    pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        traffic = json.load(open(pmc)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
+        traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, reads x2)"
     return dict(bound="mfma", kernel="igemm_kernel (implicit-GEMM conv3x3 + GEMM, v_mfma_f32_16x16x32_bf16)",
-                achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+                achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                traffic_source=traffic_src, alg_bytes_per_launch=round(alg_bytes / n_gemm),
                 launches=n_gemm, avg_launch_us=round(1e3 * t_gemm / n_gemm, 2),
                 alg_gflop_per_launch=round(flops / n_gemm / 1e9, 3),
                 conv_tflops=round(conv_f / (conv_t * 1e-3) / 1e12, 2) if conv_t else None,
