@@ -139,8 +139,10 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run: take the RCCL path even at N = 1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     from frido_amd.pipeline import sample_images, shard_range
@@ -159,7 +161,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +171,7 @@ def main():
         img = one_step(args.warmup + k)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -180,7 +182,7 @@ def main():
         eng = next(iter(rt._sampler_engines.values()))
         roof = gemm_roofline(eng, torch.cuda.current_stream().cuda_stream, args.precision)
         out = {
-            "metric": "images/sec @ DDIM-200, COCO layout2img 256x256", "value": round(total * args.steps / dt, 4),
+            "metric": f"images/sec @ DDIM-{args.ddim_steps}, COCO layout2img 256x256", "value": round(total * args.steps / dt, 4),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-emulating, fp32 accumulate)",
@@ -196,7 +198,7 @@ def main():
             # use 16 threads by default and say so in `cores`
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(16, os.cpu_count() or 1))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

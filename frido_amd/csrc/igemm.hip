@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
 
     // ---- epilogue: lane holds D[row = (lane>>4)*4 + e][col = lane & 15] of each 16x16 tile ----
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    if (d.act == 99) {      // profiling aid (tools/gemm_bench.py --no-epilogue): keep the accumulators live, store nothing
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sink == 1.2345e-30f) d.out_f32[0] = sink;
+        return;
+    }
     if (gridDim.z > 1) {      // split-K: raw partial sums; splitk_reduce_kernel applies the epilogue
         float* wsp = d.ws + (int64_t)kz * d.M * d.N;
 #pragma unroll

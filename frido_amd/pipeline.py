@@ -21,7 +21,7 @@ def all_gather_images(local, total=None, group=None):
     """One collective joining per-rank image shards [b_r, ...] -> [sum b_r, ...] on every rank.
     Equal shards use all_gather_into_tensor (a single RCCL all-gather); ragged shards are padded to the
     largest shard first."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size(group)
     total = total if total is not None else local.shape[0] * world

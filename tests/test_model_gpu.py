@@ -238,6 +238,36 @@ def test_sampler_matches_reference_golden(name, ucfg, vcfg, run):
     assert frac_bad < 0.02, frac_bad
 
 
+def test_t2i_style_config_single_token_context_cfg_plms():
+    """BASELINE config 3 shape class (configs/frido/t2i/frido_f16f8_coco_clip.yaml): split [4,4], 8 latent channels,
+    ONE context token (pooled CLIP feature), classifier-free guidance, PLMS — HIP path vs the oracle."""
+    from frido.models.diffusion.plms import PLMSSampler
+    from frido_amd.synth import seeded_normal, fill_tensor
+    from oracle import samplers as S
+    from oracle.unet import unet_forward
+    from oracle.vqgan import vq_decode
+    ucfg = dict(UNET_SMALL, split_embed_dim_list=[4, 4], in_channels=8, out_channels=8, context_dim=96)
+    vcfg = dict(VQ_SMALL, embed_dim=[4, 4], n_embed=[128, 128],
+                edconfig=dict(VQ_SMALL["edconfig"], z_channels=[4, 4]), ddconfig=dict(VQ_SMALL["ddconfig"], z_channels=8))
+    model = _frido(ucfg, vcfg)
+    B = 2
+    c = torch.from_numpy(seeded_normal("t2i:c", (B, 1, 96)))
+    uc = torch.from_numpy(seeded_normal("t2i:uc", (1, 1, 96))).repeat(B, 1, 1)
+    n = 5
+    tape = seeded_normal("t2i:noise", (B * 8 * 256 + (n + 1) * B * 4 * 256 + (n + 1) * B * 8 * 256,))
+    z, _ = PLMSSampler(model).sample(S=n, batch_size=B, shape=(8, 16, 16), conditioning=c.cuda(), num_stage=2, eta=0.0,
+                                     verbose=False, unconditional_guidance_scale=1.5, unconditional_conditioning=uc.cuda(),
+                                     noise=_Tape(tape))
+    usd = {"model.diffusion_model." + k: torch.from_numpy(fill_tensor("model.diffusion_model." + k, v.shape))
+           for k, v in model.model.diffusion_model.state_dict().items()}
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    z_ref, _ = S.plms_sample(lambda x, t, cc, s: unet_forward(usd, ucfg, x, t, cc, s), ac, n, (B, 8, 16, 16), c, [4, 4], [4, 4], 2,
+                             scale=1.5, uc=uc, noise=S.NoiseSource(tape))
+    assert _rel(z, z_ref) < 1e-3
+    img = model.decode_first_stage(z)
+    assert img.shape == (B, 3, 64, 64) and bool(torch.isfinite(img).all())
+
+
 def test_sampler_torch_seed_reproduces_reference_noise_stream():
     from frido.models.diffusion.ddim import DDIMSampler
     g = golden("sampler_small")

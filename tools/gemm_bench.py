@@ -46,6 +46,9 @@ def main():
     b.prog.run(sp)
     kind, st = b.prog.ops[-1]
     reps = 20
+    noepi = os.environ.get("NOEPI") == "1"
+    if noepi:
+        st.act = 99
     for tile in tiles:
         st.tile = tile
         arr = _lib.pack_ops([(kind, st)] * reps)
