@@ -47,7 +47,8 @@ struct Geo {
     static constexpr int PLANE = (BM + BN) * ROWB;
     static constexpr int STAGE = NS * PLANE;
     static constexpr int D = (4 * STAGE <= 98304 && NS == 1) ? 4 : 3;   // LDS ring depth
-    static constexpr int SMEM = D * STAGE;
+    static constexpr int EPI = 4 * 16 * (BN / 2 + 4) * 4;   // epilogue transpose slabs (one per wave)
+    static constexpr int SMEM = D * STAGE > EPI ? D * STAGE : EPI;
     static_assert(SMEM <= 163840, "LDS budget");
 };
 
@@ -267,9 +268,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
         buf = buf + 1 == D ? 0 : buf + 1;
     }
 
-    // ---- epilogue: lane holds D[row = (lane>>4)*4 + e][col = lane & 15] of each 16x16 tile ----
-    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-    if (d.act == 99) {      // profiling aid (tools/gemm_bench.py --no-epilogue): keep the accumulators live, store nothing
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    // MFMA leaves lane l with D[row = (l>>4)*4 + e][col = l & 15] of each 16x16 tile (16 lanes x 4 B per row segment).
+    // Each 16-row slab of the wave's sub-tile is transposed through the (now idle) LDS ring so that every lane owns 4
+    // CONSECUTIVE columns of one row: bias / timestep vector / residual come in as 16-byte loads and the results leave
+    // as 8- or 16-byte stores (the per-element form was 15-40 % of the kernel on the U-Net shapes).
+    constexpr int WR = BM / WM, WC = BN / WN, EPS = WC + 4;          // +4 floats: conflict-free slab writes
+    constexpr int LPR = WC / 4, RPP = 64 / LPR;                       // lanes per row, rows per pass
+    if (d.act == 99) {      // profiling aid (tools/gemm_bench.py NOEPI=1): keep the accumulators live, store nothing
         float sink = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -278,66 +284,99 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
         if (sink == 1.2345e-30f) d.out_f32[0] = sink;
         return;
     }
-    if (gridDim.z > 1) {      // split-K: raw partial sums; splitk_reduce_kernel applies the epilogue
-        float* wsp = d.ws + (int64_t)kz * d.M * d.N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + col_l;
-            if (n >= d.N) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = m0 + wm * (BM / WM) + i * 16 + row_l + e;
-                    if (m < d.M) wsp[(int64_t)m * d.N + n] = acc[i][j][e];
-                }
-        }
-        return;
-    }
-    if (d.geglu) {            // fused GEGLU: tile column block j holds `a`, block j+1 the matching gate
-#pragma unroll
-        for (int j = 0; j < TN; j += 2) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + col_l;
-            if (n + 16 >= d.N) continue;
-            const float ba = d.bias ? d.bias[n] : 0.f, bg = d.bias ? d.bias[n + 16] : 0.f;
-            const int oc = (n >> 5) * 16 + col_l;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = m0 + wm * (BM / WM) + i * 16 + row_l + e;
-                    if (m >= d.M) continue;
-                    const float a = acc[i][j][e] * d.alpha + ba, g = acc[i][j + 1][e] * d.alpha + bg;
-                    const float v = a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
-                    store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + oc, v);
-                }
-        }
-        return;
-    }
+    __builtin_amdgcn_s_barrier();                                      // every wave is done reading the ring
+    float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EPS);
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const int er = lane / LPR, ec = (lane - er * LPR) * 4;             // this lane's (row, first column) in a pass
+    const bool lane_on = lane < RPP * LPR;
     int vstep = 0;
     if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
+    const int nbase = n0 + wn * WC;
+    // vector path needs 16-byte (f32) / 8-byte (bf16) aligned rows
+    const bool vec_ok = ((d.ldo | d.ldr | d.ldoo | d.ldv | d.N) & 3) == 0 || (gridDim.z > 1 && (d.N & 3) == 0);
+    const int64_t of_base = (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2;
+    const int64_t oo_base = (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2;
+    const int64_t rs_base = (int64_t)zo * d.res_bs;
+    float* wsp = gridDim.z > 1 ? d.ws + (int64_t)kz * d.M * d.N : nullptr;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 16 + col_l;
-        if (n >= d.N) continue;
-        const float bias = d.bias ? d.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = acc[i][j][e];
+        if (d.geglu) {       // 16-column blocks alternate [a | gate] (attention.py:42-44): every lane makes 4 outputs
+            constexpr int LPRG = WC / 8, RPPG = 64 / LPRG;
+            const int gr = lane / LPRG, gc = (lane - gr * LPRG) * 4;          // row, first OUTPUT column of this lane
+            const int ac = (gc >> 4) * 32 + (gc & 15);                        // column of `a` inside the wave's slab
+            for (int ps = 0; ps < 16; ps += RPPG) {
+                const int r = ps + gr;
+                const int m = m0 + wm * WR + i * 16 + r;
+                const int n = nbase + ac;
+                if (lane >= RPPG * LPRG || r >= 16 || m >= d.M || n + 16 >= d.N) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac);
+                const float4 g4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac + 16);
+                float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+                if (d.bias) { ba = *reinterpret_cast<const float4*>(d.bias + n); bg = *reinterpret_cast<const float4*>(d.bias + n + 16); }
+                const float o[4] = {(a4.x * d.alpha + ba.x) * gelu_f(g4.x * d.alpha + bg.x), (a4.y * d.alpha + ba.y) * gelu_f(g4.y * d.alpha + bg.y),
+                                    (a4.z * d.alpha + ba.z) * gelu_f(g4.z * d.alpha + bg.z), (a4.w * d.alpha + ba.w) * gelu_f(g4.w * d.alpha + bg.w)};
+                store_op4(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + (n >> 5) * 16 + (n & 15), o);
+            }
+            continue;
+        }
+        for (int ps = 0; ps < 16; ps += RPP) {
+            const int r = ps + er;
+            if (!lane_on || r >= 16) continue;
+            const int m = m0 + wm * WR + i * 16 + r;
+            const int n = nbase + ec;
+            if (m >= d.M || n >= d.N) continue;
+            const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ec);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const bool full = vec_ok && n + 3 < d.N;
+            if (wsp) {                       // split-K: raw partial sums; splitk_reduce_kernel applies the epilogue
+                if (full) *reinterpret_cast<float4*>(wsp + (int64_t)m * d.N + n) = a4;
+                else for (int e = 0; e < 4 && n + e < d.N; ++e) wsp[(int64_t)m * d.N + n + e] = v[e];
+                continue;
+            }
+            const int nv = full ? 4 : min(4, d.N - n);
+            float bia[4] = {0.f, 0.f, 0.f, 0.f}, rvv[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
+            const int64_t rv_off = d.rowvec ? (int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n : 0;
+            if (full) {
+                if (d.bias) { const float4 t4 = *reinterpret_cast<const float4*>(d.bias + n); bia[0] = t4.x; bia[1] = t4.y; bia[2] = t4.z; bia[3] = t4.w; }
+                if (d.rowvec) { const float4 t4 = *reinterpret_cast<const float4*>(d.rowvec + rv_off); rvv[0] = t4.x; rvv[1] = t4.y; rvv[2] = t4.z; rvv[3] = t4.w; }
+                if (d.residual) { const float4 t4 = load_act4(d.residual, rs_base + (int64_t)m * d.ldr + n, d.res_bf16); res[0] = t4.x; res[1] = t4.y; res[2] = t4.z; res[3] = t4.w; }
+            } else {
+                for (int e = 0; e < nv; ++e) {
+                    if (d.bias) bia[e] = d.bias[n + e];
+                    if (d.rowvec) rvv[e] = d.rowvec[rv_off + e];
+                    if (d.residual) res[e] = load_act1(d.residual, rs_base + (int64_t)m * d.ldr + n + e, d.res_bf16);
+                }
+            }
+            const float rb = d.row_bias ? d.row_bias[m] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + row_l + e;
-                if (m >= d.M) continue;
-                float v = acc[i][j][e] * d.alpha + bias;
-                if (d.row_bias) v += d.row_bias[m];
-                if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
-                if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
-                else if (d.act == FRIDO_ACT_GELU) v = gelu_f(v);
-                if (d.residual) v += load_act1(d.residual, (int64_t)zo * d.res_bs + (int64_t)m * d.ldr + n, d.res_bf16);
-                if (d.out_f32)
-                    store_act1(d.out_f32, (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2 + (int64_t)m * d.ldo + n, d.out_bf16, v);
-                if (d.out_op)
-                    store_op1(d.out_op + (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
+                float x = v[e] * d.alpha + bia[e] + rb + rvv[e];
+                if (d.act == FRIDO_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (d.act == FRIDO_ACT_SILU) x = silu_f(x);
+                else if (d.act == FRIDO_ACT_GELU) x = gelu_f(x);
+                v[e] = x + res[e];
+            }
+            if (full) {
+                if (d.out_f32) {
+                    const int64_t o = of_base + (int64_t)m * d.ldo + n;
+                    if (d.out_bf16) {
+                        const uint2 pk = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
+                                                    f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+                        *reinterpret_cast<uint2*>(reinterpret_cast<frido_bf16*>(d.out_f32) + o) = pk;
+                    } else {
+                        *reinterpret_cast<float4*>(d.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+                if (d.out_op) store_op4(d.out_op + oo_base, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
+            } else {
+                for (int e = 0; e < nv; ++e) {
+                    if (d.out_f32) store_act1(d.out_f32, of_base + (int64_t)m * d.ldo + n + e, d.out_bf16, v[e]);
+                    if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n + e, v[e]);
+                }
             }
         }
     }
