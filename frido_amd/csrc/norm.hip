@@ -106,6 +106,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         s_sh[c] = d.bias[c] - s_mean[g] * sc;
     }
     __syncthreads();
+    // bf16 stream fast path: 8 channels (16 B) per lane per tensor
+    if (d.x_bf16 && (!d.gamma || d.gb_bf16) && d.nsplit == 1 && !d.out_f32 && ((d.C1 | d.C2) & 7) == 0) {
+        const unsigned C8 = (unsigned)C >> 3;
+        const unsigned total8 = (unsigned)d.HW * C8;
+        const frido_bf16* xb1 = reinterpret_cast<const frido_bf16*>(d.x1);
+        const frido_bf16* xb2 = reinterpret_cast<const frido_bf16*>(d.x2);
+        const frido_bf16* gb = reinterpret_cast<const frido_bf16*>(d.gamma);
+        const frido_bf16* bb = reinterpret_cast<const frido_bf16*>(d.beta);
+        for (unsigned i = blockIdx.x * 256u + t; i < total8; i += gridDim.x * 256u) {
+            const unsigned p = i / C8;
+            const int c = (int)(i - p * C8) * 8;
+            const int64_t pix = (int64_t)b * d.HW + p;
+            const int64_t o = pix * C + c;
+            const u32x4 xv = c < d.C1 ? *reinterpret_cast<const u32x4*>(xb1 + pix * d.C1 + c)
+                                      : *reinterpret_cast<const u32x4*>(xb2 + pix * d.C2 + (c - d.C1));
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[2 * e] = fmaf(__uint_as_float(xv[e] << 16), s_sc[c + 2 * e], s_sh[c + 2 * e]);
+                y[2 * e + 1] = fmaf(__uint_as_float(xv[e] & 0xffff0000u), s_sc[c + 2 * e + 1], s_sh[c + 2 * e + 1]);
+            }
+            if (d.gamma) {
+                const u32x4 gv = *reinterpret_cast<const u32x4*>(gb + o);
+                const u32x4 bv = *reinterpret_cast<const u32x4*>(bb + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[2 * e] = fmaf(y[2 * e], 1.f + __uint_as_float(gv[e] << 16), __uint_as_float(bv[e] << 16));
+                    y[2 * e + 1] = fmaf(y[2 * e + 1], 1.f + __uint_as_float(gv[e] & 0xffff0000u), __uint_as_float(bv[e] & 0xffff0000u));
+                }
+            }
+            if (d.act == FRIDO_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+            }
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = f32_to_bf16_bits(y[2 * e]) | (f32_to_bf16_bits(y[2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>(d.out_op + o) = ov;
+            if (d.raw_op) *reinterpret_cast<u32x4*>(d.raw_op + o) = xv;       // concatenated raw operand for the 1x1 skip conv
+        }
+        return;
+    }
     const unsigned total = (unsigned)d.HW * (unsigned)C4;      // < 2^31 on every shape of this path
     for (unsigned i = blockIdx.x * 256u + t; i < total; i += gridDim.x * 256u) {
         const unsigned p = i / (unsigned)C4;
