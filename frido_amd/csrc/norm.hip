@@ -29,8 +29,38 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
     const int p0 = sp * ppx, p1 = min(d.HW, p0 + ppx);
     const int pl = t / TC, tc = t - pl * TC;
     const int cpg = C / d.groups;
-    // one pass per 256-column chunk (a single pass whenever C <= 1024)
     double gsum = 0.0, gsq = 0.0;
+    if (d.x_bf16 && ((d.C1 | d.C2) & 7) == 0 && (C >> 3) <= 256) {
+        // bf16 stream fast path: thread owns 8 channels (16-B loads), PL8 pixel lanes per workgroup
+        const int C8 = C >> 3, PL8 = 256 / C8;
+        const int pl8 = t / C8, tc8 = t - pl8 * C8;
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pl8 < PL8) {
+            const int c = tc8 * 8;
+            const frido_bf16* base = reinterpret_cast<const frido_bf16*>(c < d.C1 ? d.x1 : d.x2);
+            const int cw = c < d.C1 ? d.C1 : d.C2, co = c < d.C1 ? c : c - d.C1;
+            for (int p = p0 + pl8; p < p1; p += PL8) {
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(base + ((int64_t)b * d.HW + p) * cw + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(xv[e] << 16), hi = __uint_as_float(xv[e] & 0xffff0000u);
+                    s8[2 * e] += lo; q8[2 * e] += lo * lo;
+                    s8[2 * e + 1] += hi; q8[2 * e + 1] += hi * hi;
+                }
+            }
+        }
+        for (int l = 0; l < PL8; ++l) {       // fixed-order combine of the pixel lanes
+            if (pl8 == l) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (l == 0) { s_sum[tc8 * 8 + e] = s8[e]; s_sq[tc8 * 8 + e] = q8[e]; }
+                    else { s_sum[tc8 * 8 + e] += s8[e]; s_sq[tc8 * 8 + e] += q8[e]; }
+                }
+            }
+            __syncthreads();
+        }
+    } else
+    // one pass per 256-column chunk (a single pass whenever C <= 1024)
     for (int cbase = 0; cbase < C4; cbase += TC) {
         const int c4 = cbase + tc;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
@@ -183,6 +213,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= d.rows) return;
+    if (d.x_bf16 && (d.C & 7) == 0 && d.nsplit == 1 && !d.out_f32) {
+        // bf16 stream fast path: 16-byte loads / stores, up to two 8-channel chunks per lane (C <= 1024)
+        const int C8 = d.C >> 3;
+        const frido_bf16* xb = reinterpret_cast<const frido_bf16*>(d.x) + (int64_t)row * d.C;
+        float x[2][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c8 = lane + i * 64;
+            if (c8 < C8) {
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[i][2 * e] = __uint_as_float(xv[e] << 16); x[i][2 * e + 1] = __uint_as_float(xv[e] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[i][e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[i][e];
+        }
+        const float mean = wave_sum(s) / d.C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane + i * 64 < C8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float a = x[i][e] - mean; q += a * a; }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / d.C + d.eps);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c8 = lane + i * 64;
+            if (c8 < C8) {
+                u32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c8 * 8 + 2 * e;
+                    const float y0 = (x[i][2 * e] - mean) * rstd * d.weight[c] + d.bias[c];
+                    const float y1 = (x[i][2 * e + 1] - mean) * rstd * d.weight[c + 1] + d.bias[c + 1];
+                    ov[e] = f32_to_bf16_bits(y0) | (f32_to_bf16_bits(y1) << 16);
+                }
+                *reinterpret_cast<u32x4*>(d.out_op + (int64_t)row * d.C + c8 * 8) = ov;
+            }
+        }
+        return;
+    }
     const int C4 = d.C >> 2;
     float4 v[4];
     float s = 0.f;
