@@ -40,23 +40,26 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int BM, int BN, int NS, int BK>
 struct Geo {
+    static constexpr int WMW = BM >= 256 ? 4 : 2;           // waves along M (x 2 along N): 4 or 8 waves per workgroup
+    static constexpr int NW = WMW * 2, NT = NW * 64;
     static constexpr int ROWB = BK * 2;                     // bytes per LDS row
     static constexpr int CHR = 1024 / ROWB;                 // rows per 1-KiB LDS-DMA chunk (16 / 8)
-    static constexpr int JA = BM / (4 * CHR), JB = BN / (4 * CHR);   // chunks per wave per plane
+    static constexpr int JA = BM / (NW * CHR), JB = BN / (NW * CHR);   // chunks per wave per plane
+    static_assert(JA * NW * CHR == BM && JB * NW * CHR == BN, "tile not divisible into per-wave DMA chunks");
     static constexpr int LPT = (JA + JB) * NS;              // LDS-DMA instructions per thread per k-tile
     static constexpr int PLANE = (BM + BN) * ROWB;
     static constexpr int STAGE = NS * PLANE;
     static constexpr int D = (4 * STAGE <= 98304 && NS == 1) ? 4 : 3;   // LDS ring depth
-    static constexpr int EPI = 4 * 16 * (BN / 2 + 4) * 4;   // epilogue transpose slabs (one per wave)
+    static constexpr int EPI = NW * 16 * (BN / 2 + 4) * 4;  // epilogue transpose slabs (one per wave)
     static constexpr int SMEM = D * STAGE > EPI ? D * STAGE : EPI;
     static_assert(SMEM <= 163840, "LDS budget");
 };
 
 template <int BM, int BN, int NS, bool CONV, int BK>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
+__global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW == 8 ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
     using G = Geo<BM, BN, NS, BK>;
     constexpr int ROWB = G::ROWB, CHR = G::CHR, KS = BK / 32;
-    constexpr int WM = 2, WN = 2;
+    constexpr int WM = G::WMW, WN = 2, NW = G::NW;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int D = G::D, JA = G::JA, JB = G::JB, PLANE = G::PLANE, STAGE = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     int a_b[JA], a_oy[JA], a_ox[JA];
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-        const int row = (wave + 4 * j) * CHR + lrow;
+        const int row = (wave + NW * j) * CHR + lrow;
         int m = m0 + row;
         if (CONV) {
             const bool okm = m < d.M;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
     int64_t b_off[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        const int row = (wave + 4 * j) * CHR + lrow;
+        const int row = (wave + NW * j) * CHR + lrow;
         int n = n0 + row;
         n = n < d.N ? n : d.N - 1;
         b_off[j] = (int64_t)n * d.ldb + lq * 8;
@@ -171,14 +174,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     src = ok ? Ab + (p ? a_lo : 0) + off : reinterpret_cast<const frido_bf16*>(zero_addr);
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * 4096), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * (NW * 1024)), 16, 0, 0);
                 }
             } else {
                 const int64_t off = a_off[j] + (int64_t)kt * BK;
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     src = Ab + (p ? a_lo : 0) + off;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * 4096), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * (NW * 1024)), 16, 0, 0);
                 }
             }
         }
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const FridoGemm d) {
 #pragma unroll
             for (int p = 0; p < NS; ++p)
                 __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (p ? b_lo : 0) + off),
-                                                 (lptr_t)(sb + p * PLANE + BM * ROWB + j * 4096), 16, 0, 0);
+                                                 (lptr_t)(sb + p * PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
         }
         if (CONV) {   // advance the (tap, channel) walk
             kc += BK;
@@ -418,7 +421,7 @@ int launch(const FridoGemm& d, hipStream_t s) {
     constexpr int smem = Geo<BM, BN, NS, BK>::SMEM;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const int sk = d.splitk > 1 ? d.splitk : 1;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK>), dim3(tiles, d.batch, sk), dim3(256), smem, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK>::NT), smem, s, d);
     if (sk > 1) {
         const int64_t total = (int64_t)d.M * d.N;
         const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
@@ -436,6 +439,10 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         case 5: return launch<64, 192, NS, CONV, 32>(d, s);
         case 6: return launch<64, 128, NS, CONV, 32>(d, s);
         default: break;
+    }
+    if constexpr (NS == 1) {      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
+        if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);
+        if (tile == 8) return launch<256, 256, NS, CONV, 32>(d, s);
     }
     if constexpr (NS == 1) {      // BK = 64 variants (bf16 mode only: the bf16x3 planes would not fit the LDS budget)
         const bool k64 = (d.K & 63) == 0 && (!CONV || (d.Cin & 63) == 0);
@@ -473,6 +480,8 @@ int frido_igemm_init() {
     FRIDO_SET_ALL(128, 128); FRIDO_SET_ALL(128, 192); FRIDO_SET_ALL(64, 64);
     FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
 #undef FRIDO_SET_ALL
+    rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
+          set_attr<256, 256, 1, false, 32>();
     return rc ? FRIDO_EHIP : FRIDO_OK;
 }
 

@@ -10,6 +10,7 @@ from . import _lib
 
 TILES = (1, 2, 3, 4, 5, 6)          # see include/frido_hip.h FridoGemm.tile
 TILES64 = (11, 12, 13, 14, 15, 16)  # BK = 64 variants
+TILES8W = (7, 8)                    # 8-wave 256-row tiles (bf16 mode)
 _cache = {}
 _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
@@ -95,7 +96,8 @@ def best_tile(st, device, stream):
         # BK = 64 halves the barrier count but costs a ring stage of occupancy: it only wins on small-M shapes
         k64 = (st.nsplit == 1 and st.K % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
                and st.M * st.batch <= 4096)
-        for tile in TILES + (TILES64 if k64 else ()):
+        big = st.nsplit == 1 and sk == 1 and st.M >= 512 and st.N >= 96
+        for tile in TILES + (TILES64 if k64 else ()) + (TILES8W if big else ()):
             if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue
             if sk > 1 and tile % 10 in (1, 2):

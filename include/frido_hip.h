@@ -79,6 +79,7 @@ typedef struct FridoGemm {
                                    second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
     float* ws;
     int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 (BK 32);
+                                   7 = 256x128, 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64) */
 } FridoGemm;
 

@@ -114,12 +114,12 @@ def test_gemm_split_k_is_deterministic_and_correct(nsplit, conv, splitk, tile):
     assert torch.equal(first, out.view())        # fixed-order reduction: bit-reproducible
 
 
-@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("tile", [7, 8, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("conv", [False, True])
-def test_gemm_bk64_variants(tile, conv):
+def test_gemm_bk64_and_8wave_variants(tile, conv):
     from frido_amd.builder import ACT_SILU
     if conv:
-        B, H, W, Cin, Cout = 2, 12, 10, 128, 200
+        B, H, W, Cin, Cout = 3, 12, 10, 128, 200
         x, w, bias = _t("qx", B, Cin, H, W), _t("qw", Cout, Cin, 3, 3) / np.sqrt(9 * Cin), _t("qb", Cout)
         ref = F.silu(F.conv2d(x, w, bias, padding=1)).permute(0, 2, 3, 1).reshape(-1, Cout)
         b = _builder(1, {"c.weight": w.cuda(), "c.bias": bias.cuda()})
