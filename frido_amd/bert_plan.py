@@ -4,23 +4,10 @@ LayerNorm -> fused QK projection + transposed V projection -> (batch x head) QK^
 -> output projection (+residual) -> LayerNorm -> Linear+GELU -> Linear (+residual); final LayerNorm -> f32 context."""
 import torch
 
-from .builder import Builder, ACT_NONE
+from .builder import Builder
 from .engine import rup
 
 ACT_GELU = 3
-
-
-class _T:
-    def __init__(self, t, bf16=False):
-        self.t, self.bf16 = t, bf16
-        self.rows, self.C = t.shape[0], t.shape[1]
-
-    @property
-    def ptr(self):
-        return self.t.data_ptr()
-
-    def free(self):
-        pass
 
 
 class BertPlan:

@@ -14,7 +14,6 @@ import torch.nn as nn
 
 from . import config, holders, schedules
 from ._lib import FridoHipError
-from .arch import unet_arch
 
 try:  # pytorch-lightning is optional (absent in this image): keep the LightningModule base when it exists
     import pytorch_lightning as _pl

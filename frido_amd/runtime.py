@@ -12,7 +12,7 @@ import torch
 from . import _lib, config
 from .builder import Builder
 from .engine import current_stream_ptr, require_gpu
-from .schedules import sampler_coef_table, COEF_ROW
+from .schedules import sampler_coef_table
 from .unet_plan import UNetStagePlan
 from .vqgan_plan import VQDecodePlan, VQEncodePlan
 

@@ -19,7 +19,7 @@ from .engine import rup
 
 class UNetStagePlan:
     def __init__(self, b: Builder, cfg, *, B, H, W, nctx, stage, x_state, temb_rows, per_sample_t, step_ptr=None,
-                 xrep=1, hoist=True):
+                 xrep=1):
         """x_state: f32 device tensor [B][H*W][Ctot] (NHWC latent).  The denoiser runs on a logical batch
         Bx = B * xrep (xrep = 2 for classifier-free guidance: [cond | uncond] share x, differ in context).
         temb_rows: number of rows of the timestep table (S in sampler mode, Bx when per_sample_t)."""
@@ -40,7 +40,6 @@ class UNetStagePlan:
         self.c0 = sum(a.splits[:stage]) if (a.use_split_head and a.use_spade) else 0
         self.c1 = sum(a.splits[:stage + 1]) if a.use_split_head else a.in_channels
         self.spade_on = a.use_spade and self.c0 > 0
-        self.taps = {}
         # names of every ResBlock in forward order (for the concatenated emb_layers projection)
         self.res_names = [blk.prefix for grp in (a.input_blocks + [a.middle] + a.output_blocks) for blk in grp
                           if blk.kind == "res"]
@@ -145,7 +144,6 @@ class UNetStagePlan:
         """(SPADE module prefix, channels, resolution level) for every SPADE instance in forward order."""
         a = self.a
         out, lvl = [], 0
-        cat_in = {}
         for grp in a.input_blocks:
             for blk in grp:
                 if blk.kind == "res":
@@ -180,7 +178,6 @@ class UNetStagePlan:
         return b.groupnorm(x1, x2, self.Bx, HW, name, eps, act=act, want_raw=want_raw)
 
     def _rowvec(self, ridx):
-        HW_all = None
         d = dict(ptr=self.E.data_ptr() + 4 * int(self.res_off[ridx]), ld=int(self.res_off[-1]))
         if self.per_sample_t:
             d["rows_per_vec"] = None     # filled by caller (HW at that resolution)
@@ -270,7 +267,6 @@ class UNetStagePlan:
         hs = [(hcur, H, W)]
         h, w = H, W
         ridx = 0
-        owned = None   # current tensor if it is NOT on the skip stack (must be freed by us)
         for grp in a.input_blocks:
             cur = hs[-1][0]
             first = True
@@ -300,7 +296,6 @@ class UNetStagePlan:
             if cur is not mid_in:
                 cur.free()
             cur = nxt
-        self._tap("mid", cur, h, w)
         for grp in a.output_blocks:
             skip, sh, sw = hs.pop()
             assert (sh, sw) == (h, w)
@@ -327,9 +322,6 @@ class UNetStagePlan:
         b.conv(ao, self.Bx, h, w, o + ".2", out=("f32", self._T(self.eps)))
         ao.free()
         return prog
-
-    def _tap(self, name, t, h, w):
-        pass
 
     # ------------------------------------------------------------------------------------------
     def set_context(self, ctx):

@@ -40,6 +40,23 @@ def test_unet_forward_matches_reference_golden(name, cfg):
         assert _rel(e, g[f"eps_{s}"]) < 2e-4, (name, s)
 
 
+@pytest.mark.parametrize("B,H,W,nctx", [(1, 16, 16, 5), (3, 16, 8, 1), (2, 8, 24, 33)])
+def test_unet_forward_ragged_shapes_vs_oracle(B, H, W, nctx):
+    """Edge shapes: batch 1 / odd batch, non-square latents, 1 and 33 context tokens (pad paths), per-sample timesteps."""
+    from oracle.unet import unet_forward
+    from frido_amd.synth import seeded_normal
+    m = _unet(UNET_SMALL)
+    sd = synth_sd(unet_holder(UNET_SMALL), "model.diffusion_model.")
+    x = torch.from_numpy(seeded_normal("rag:x", (B, 6, H, W)))
+    ctx = torch.from_numpy(seeded_normal("rag:c", (B, nctx, 64)))
+    t = torch.tensor([11 + 300 * i for i in range(B)])
+    for s in (0, 1):
+        xin = x[:, :3 * (s + 1)].contiguous()
+        ref = unet_forward(sd, UNET_SMALL, xin, t, ctx, s)
+        got = m(xin.cuda(), t.cuda(), context=ctx.cuda(), stage=s)
+        assert got.shape == ref.shape and _rel(got, ref) < 2e-4, (B, H, W, s)
+
+
 def test_unet_forward_bf16_mode_within_bf16_tolerance():
     g = golden("unet_small")
     from frido_amd.models import PyUNetModel
