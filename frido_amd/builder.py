@@ -109,6 +109,36 @@ class Builder:
         return self.dev_f32(name).data_ptr() if name in self.w else None
 
     # ---- ops -----------------------------------------------------------------------------------
+    def conv_plus_skip_weight(self, wname, skip_wname):
+        """[Cout][9*Cin_pad | Cskip_pad64] weight of a 3x3 conv with a 1x1 skip conv appended along K, and the summed bias."""
+        key = ("conv+skip", wname, skip_wname)
+        if key not in self._wcache:
+            w = self.w[wname + ".weight"].float()
+            co, ci, kh, kw = w.shape
+            cp = rup(ci, 32)
+            wk = torch.zeros((co, kh, kw, cp), dtype=torch.float32, device=w.device)
+            wk[..., :ci] = w.permute(0, 2, 3, 1)
+            ws = self.w[skip_wname + ".weight"].float().reshape(co, -1)
+            k2 = rup(ws.shape[1], 64)
+            wsk = torch.zeros((co, k2), dtype=torch.float32, device=w.device)
+            wsk[:, :ws.shape[1]] = ws
+            bsum = (self.w[wname + ".bias"].float() + self.w[skip_wname + ".bias"].float()).contiguous()
+            self._wcache[key] = (pack_matrix(torch.cat([wk.reshape(co, -1), wsk], dim=1), self.nsplit), cp, k2, bsum)
+        return self._wcache[key]
+
+    def conv_plus_skip(self, a, raw, B, H, W, wname, skip_wname, out="f32"):
+        """out = conv3x3(a) + conv1x1(raw) in ONE implicit GEMM (the 1x1 rides along as an extra K range)."""
+        wop, cp, k2, bsum = self.conv_plus_skip_weight(wname, skip_wname)
+        w = self.w[wname + ".weight"]
+        co, _, kh, kw = w.shape
+        assert a.K == cp and raw.K % 64 == 0 and raw.K == k2 and (kh * kw * cp) % 64 == 0
+        M = B * H * W
+        geom = dict(Hs=H, Ws=W, Cin=cp, Hl=H, Wl=W, Ho=H, Wo=W, kh=kh, kw=kw, stride=1, pad=1, up_shift=0, dn_shift=0)
+        res = self.f32(M, co)
+        self.prog.gemm(M, co, kh * kw * cp, a, wop, ldb=kh * kw * cp + k2, conv=geom, bias=bsum.data_ptr(), out_f32=res.ptr, ldo=co,
+                       out_bf16=res.bf16, A2=raw, lda2=raw.K, K2=k2)
+        return res
+
     def conv(self, a, B, Hs, Ws, wname, *, stride=1, pad=1, up=0, dn=0, Ho=None, Wo=None, bias=True,
              rowvec=None, act=ACT_NONE, residual=None, out="f32", alpha=1.0):
         """3x3 / 1x1 convolution of the NHWC operand `a` ([B*Hs*Ws][Cin_pad]).

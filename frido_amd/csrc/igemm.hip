@@ -125,6 +125,15 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             a_off[j] = (int64_t)m * d.lda + lq * 8;
         }
     }
+    int64_t a2_off[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        int m = m0 + (wave + NW * j) * CHR + lrow;
+        m = m < d.M ? m : d.M - 1;
+        a2_off[j] = (int64_t)m * d.lda2 + lq * 8;
+    }
+    const frido_bf16* __restrict__ A2b = d.A2;
+    const int nk1 = d.K / BK;                 // k-tiles of the primary A operand
     int64_t b_off[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     }
 
     // k-tile range of this workgroup (split-K: gridDim.z slices)
-    const int nk_all = d.K / BK;
+    const int nk_all = (d.K + d.K2) / BK;
     const int kz = blockIdx.z;
     const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kt0 = kz * per;
@@ -161,7 +170,13 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
             const frido_bf16* src;
-            if (CONV) {
+            if (kt >= nk1) {                 // appended dense operand (fused 1x1 skip conv)
+                const int64_t off = a2_off[j] + (int64_t)(kt - nk1) * BK;
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(A2b + (p ? d.a2_lo : 0) + off),
+                                                     (lptr_t)(sb + p * PLANE + j * (NW * 1024)), 16, 0, 0);
+            } else if (CONV) {
                 const bool ok = (a_mask[j] >> tap) & 1u;
                 int64_t off;
                 if (resample) {   // Upsample / SPADE-resize convs: source pixel = ((iy >> up) << dn, (ix >> up) << dn)
@@ -193,7 +208,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (p ? b_lo : 0) + off),
                                                  (lptr_t)(sb + p * PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
         }
-        if (CONV) {   // advance the (tap, channel) walk
+        if (CONV && kt < nk1) {   // advance the (tap, channel) walk
             kc += BK;
             tap_off += BK;
             if (kc == cin) {
@@ -445,7 +460,7 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         if (tile == 8) return launch<256, 256, NS, CONV, 32>(d, s);
     }
     if constexpr (NS == 1) {      // BK = 64 variants (bf16 mode only: the bf16x3 planes would not fit the LDS budget)
-        const bool k64 = (d.K & 63) == 0 && (!CONV || (d.Cin & 63) == 0);
+        const bool k64 = (d.K & 63) == 0 && (d.K2 & 63) == 0 && (!CONV || (d.Cin & 63) == 0);
         if (k64) switch (tile) {
             case 11: return launch<128, 128, NS, CONV, 64>(d, s);
             case 12: return launch<128, 192, NS, CONV, 64>(d, s);
@@ -489,7 +504,8 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     FRIDO_REQUIRE(dp != nullptr, "null descriptor");
     const FridoGemm& d = *dp;
     FRIDO_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, "empty problem");
-    FRIDO_REQUIRE((d.K & 31) == 0, "K must be a multiple of 32 (zero-pad the operands)");
+    FRIDO_REQUIRE((d.K & 31) == 0 && (d.K2 & 63) == 0, "K must be a multiple of 32, K2 of 64 (zero-pad the operands)");
+    FRIDO_REQUIRE(d.K2 == 0 || (d.A2 && (d.lda2 & 7) == 0 && (d.K & 63) == 0 && d.batch == 1), "bad second A operand");
     FRIDO_REQUIRE(d.nsplit == 1 || d.nsplit == 2, "nsplit must be 1 or 2");
     FRIDO_REQUIRE(d.A && d.B, "null operand");
     FRIDO_REQUIRE(d.out_f32 || d.out_op, "no output");
@@ -511,7 +527,7 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     }
     if (d.splitk > 1) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
-        FRIDO_REQUIRE(d.splitk <= (d.K >> 6), "more K slices than k-tiles");
+        FRIDO_REQUIRE(d.splitk <= ((d.K + d.K2) >> 6), "more K slices than k-tiles");
     }
     const int tile = d.tile ? d.tile : pick_tile(d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

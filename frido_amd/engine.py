@@ -194,7 +194,7 @@ class Prog:
     def gemm(self, M, N, K, A, B, *, batch=1, lda=None, ldb=None, a_bs=0, b_bs=0, a_lo=None, b_lo=None,
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
              residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
-             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0):
+             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0, A2=None, lda2=0, K2=0):
         """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
         ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
@@ -204,6 +204,8 @@ class Prog:
                   of_bs2=of_bs2, oo_bs2=oo_bs2)
         if conv:
             kw.update(conv=1, **conv)
+        if A2 is not None:
+            kw.update(A2=A2.ptr, a2_lo=A2.lo, lda2=lda2, K2=K2)
         if bias is not None:
             kw["bias"] = bias
         if row_bias is not None:
@@ -225,7 +227,7 @@ class Prog:
             st.tile, st.splitk = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
             if st.splitk > 1:
                 st.ws = tune.workspace(self.device, st.splitk * M * N * 4)
-        self.flops += 2 * M * N * K * batch * (3 if self.nsplit == 2 else 1)
+        self.flops += 2 * M * N * (K + K2) * batch * (3 if self.nsplit == 2 else 1)
 
     # ---- execution ---------------------------------------------------------------------------
     def packed(self):

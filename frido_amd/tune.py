@@ -17,7 +17,7 @@ ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
 
 _SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
                "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
-               "res_bs", "res_bf16", "out_bf16", "batch_inner", "a_bs2", "b_bs2", "of_bs2", "oo_bs2")
+               "res_bs", "res_bf16", "out_bf16", "batch_inner", "a_bs2", "b_bs2", "of_bs2", "oo_bs2", "K2", "lda2")
 
 
 def _buf(name, nbytes, device):
@@ -66,6 +66,9 @@ def best_tile(st, device, stream):
     a_elems, b_elems = (a_elems + 7) // 8 * 8, (b_elems + 7) // 8 * 8
     t.A, t.a_lo = _buf("A", a_elems * 2 * ns, device), a_elems
     t.B, t.b_lo = _buf("B", b_elems * 2 * ns, device), b_elems
+    if st.K2:
+        a2 = (st.M * st.lda2 + 7) // 8 * 8
+        t.A2, t.a2_lo = _buf("A2", a2 * 2 * ns, device), a2
     rows = st.M * st.batch
     if st.out_f32:
         t.out_f32 = _buf("O", max(max(st.of_bs, st.of_bs2) * st.batch, st.M * st.ldo) * 4 + 4096, device)
@@ -87,14 +90,14 @@ def best_tile(st, device, stream):
     kind = _lib.OP_KINDS["FRIDO_OP_GEMM"]
     reps = 5
     best, best_t = (0, 1), float("inf")
-    nk = st.K // 32
+    nk = (st.K + st.K2) // 32
     small = st.batch == 1 and st.M * st.N <= (1 << 23) and not st.geglu       # split-K only pays for small outputs with a long K
     splits = [1] + [k for k in (2, 4, 8) if small and nk >= 8 * k]
     for sk in splits:
         t.splitk = sk
         t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None
         # BK = 64 halves the barrier count but costs a ring stage of occupancy: it only wins on small-M shapes
-        k64 = (st.nsplit == 1 and st.K % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
+        k64 = (st.nsplit == 1 and st.K % 64 == 0 and st.K2 % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
                and st.M * st.batch <= 4096)
         big = st.nsplit == 1 and sk == 1 and st.M >= 512 and st.N >= 96
         for tile in TILES + (TILES64 if k64 else ()) + (TILES8W if big else ()):

@@ -199,7 +199,10 @@ class UNetStagePlan:
         a1.free()
         a2, _ = self._norm(hmid, None, HW, pre + ".out_layers.0", 1e-5, ACT_SILU)
         hmid.free()
-        if has_skip:
+        if has_skip and raw.K % 64 == 0 and a2.K % 64 == 0:
+            out = b.conv_plus_skip(a2, raw, self.Bx, h, w, pre + ".out_layers.3", pre + ".skip_connection")
+            raw.free()
+        elif has_skip:
             res = b.linear(raw, pre + ".skip_connection")
             raw.free()
             out = b.conv(a2, self.Bx, h, w, pre + ".out_layers.3", residual=res, out=("f32", res))

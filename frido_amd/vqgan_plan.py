@@ -36,7 +36,10 @@ def vq_res(b, B, blk_prefix, x, h, w):
     a1.free()
     a2, _ = b.groupnorm(hmid, None, B, HW, pre + ".norm2", 1e-6, act=ACT_SILU)
     hmid.free()
-    if has_nin:
+    if has_nin and raw.K % 64 == 0 and a2.K % 64 == 0:
+        out = b.conv_plus_skip(a2, raw, B, h, w, pre + ".conv2", pre + ".nin_shortcut")
+        raw.free()
+    elif has_nin:
         res = b.linear(raw, pre + ".nin_shortcut")
         raw.free()
         out = b.conv(a2, B, h, w, pre + ".conv2", residual=res, out=("f32", res))

@@ -59,6 +59,9 @@ typedef struct FridoGemm {
     int32_t Hl, Wl;             /* conv: logical (resized) input dims */
     int32_t Ho, Wo;             /* conv: output dims; M = Bimg*Ho*Wo */
     int32_t kh, kw, stride, pad, up_shift, dn_shift;
+    /* optional second A operand appended along K: k in [K, K + K2) reads the dense matrix A2[m][k - K] (lda2).  Used to
+       fold the ResBlock's 1x1 skip conv (pyunet.py:248,300; taming model.py:131-135) into the second 3x3 conv. */
+    const frido_bf16* A2; int64_t a2_lo; int32_t lda2, K2;
     const frido_bf16* B; int64_t b_lo; int64_t b_bs; int32_t ldb;
     float alpha;
     const float* bias;          /* [N] per output column */
