@@ -49,11 +49,26 @@ struct Geo {
     static constexpr int LPT = (JA + JB) * NS;              // LDS-DMA instructions per thread per k-tile
     static constexpr int PLANE = (BM + BN) * ROWB;
     static constexpr int STAGE = NS * PLANE;
-    static constexpr int D = (4 * STAGE <= 98304 && NS == 1) ? 4 : 3;   // LDS ring depth
+    // LDS ring depth.  4-wave tiles: 3-4 stages -- a deeper ring costs resident workgroups per CU, and on the U-Net's
+    // many-workgroup shapes occupancy hides latency better than bytes in flight (measured: 8 stages = -20 % on
+    // 16384x384x384).  8-wave tiles own the CU, so they take what fits.
+    static constexpr int D8 = 147456 / STAGE > 6 ? 6 : 147456 / STAGE;
+    static constexpr int D = NW == 8 ? D8 : ((4 * STAGE <= 98304 && NS == 1) ? 4 : 3);
     static constexpr int EPI = NW * 16 * (BN / 2 + 4) * 4;  // epilogue transpose slabs (one per wave)
     static constexpr int SMEM = D * STAGE > EPI ? D * STAGE : EPI;
     static_assert(SMEM <= 163840, "LDS budget");
 };
+
+// drain phase of the ring: `rem` (< D-2) younger tiles are still in flight, each LPT loads per thread
+template <int R, int LPT>
+__device__ __forceinline__ void wait_tail(int rem) {
+    if constexpr (R <= 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (rem >= R) wait_vmcnt<R * LPT>();
+        else wait_tail<R - 1, LPT>(rem);
+    }
+}
 
 template <int BM, int BN, int NS, bool CONV, int BK>
 __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW == 8 ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
@@ -243,7 +258,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed: at most the loads of the (D-2) younger tiles may stay in flight
         if (kt + D - 2 < nk) wait_vmcnt<(D - 2) * G::LPT>();
-        else wait_vmcnt<0>();
+        else wait_tail<D - 3, G::LPT>(nk - 1 - kt);
         __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is visible; stage (kt-1)%D is free
         if (kt + D - 1 < nk) {
             int nb_ = buf + D - 1;

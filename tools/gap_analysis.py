@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Idle-gap analysis of one captured sampling pass from a rocprofv3 kernel trace.
+   rocprofv3 --kernel-trace --output-format csv -d DIR -- python bench.py --steps 1 --warmup 0
+   python tools/gap_analysis.py DIR > summary.json
+Takes the kernels after the last randn_kernel (= the last sampling pass + decode), and reports wall time, the union of
+kernel intervals (busy), the idle remainder, and the per-kernel-name totals."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    last = max(i for i, r in enumerate(rows) if "randn_kernel" in r[2])
+    rows = rows[last:]
+    wall = rows[-1][1] - rows[0][0]
+    busy, cur_end, gaps = 0, rows[0][0], []
+    for s, e, _ in rows:
+        if s > cur_end:
+            gaps.append(s - cur_end)
+            busy += e - s
+            cur_end = e
+        elif e > cur_end:
+            busy += e - cur_end
+            cur_end = e
+    per = defaultdict(lambda: [0, 0])
+    for s, e, n in rows:
+        k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        per[k][0] += 1
+        per[k][1] += e - s
+    gaps.sort()
+    out = {"kernels": len(rows), "wall_ms": wall / 1e6, "busy_ms": busy / 1e6, "idle_ms": (wall - busy) / 1e6,
+           "idle_frac": (wall - busy) / wall, "sum_dur_ms": sum(e - s for s, e, _ in rows) / 1e6,
+           "gap_us_median": gaps[len(gaps) // 2] / 1e3 if gaps else 0, "gap_us_p90": gaps[int(len(gaps) * .9)] / 1e3 if gaps else 0,
+           "n_gaps": len(gaps),
+           "per_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
