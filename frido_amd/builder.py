@@ -273,6 +273,13 @@ class Builder:
         """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
         [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158)."""
         Np = rup(Nk, 32)
+        if Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0:
+            # short key sequence: one fused launch, scores stay on chip
+            o = self.op(B * Nq, d)
+            self.prog.emit("FRIDO_OP_ATTN_SMALL", Q=q.ptr + 2 * q_off, q_lo=q.lo, ldq=ldq, K=k.ptr + 2 * k_off, k_lo=k.lo,
+                           k_bs=Nk * ldk, ldk=ldk, VT=vT.ptr, vt_lo=vT.lo, vt_bs=d * Np, ldvt=Np, out_op=o.ptr, out_lo=o.lo,
+                           ldo=d, B=B, Nq=Nq, Nk=Nk, d=d, dv=d, nsplit=self.nsplit, alpha=float(d) ** -0.5)
+            return o
         s = self.f32_strict(B * Nq, Nk)
         self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
                        a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)

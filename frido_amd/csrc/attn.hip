@@ -1,0 +1,232 @@
+// Fused attention core for short key sequences (gfx950): O = softmax(alpha * Q K^T) V with Nk <= 128 keys, one launch,
+// the score matrix living in registers / LDS only.  Replaces the QK^T GEMM -> row softmax -> PV GEMM chain of the
+// U-Net's cross-attention (Nk = 26 / 92 / 1 context tokens) and of self-attention on its 8x8 plane
+// (frido/modules/attention.py:170-193).  Those launches move a few hundred KB each and were pure launch latency.
+//
+// One workgroup = 16 query rows x NW waves (4, 8 or 16).
+//   phase 1  the d/32 k-steps of S = Q K^T are dealt round-robin to the waves; every lane feeds the MFMA straight from
+//            global memory (16-byte operand loads, K rows clamped to the last valid key); partial scores go to LDS.
+//   phase 2  the 16 rows are dealt to the waves: each sums the partials (fixed order), scales, masks keys >= Nk, softmax with wave reductions, and
+//            leaves P as bf16 (hi / lo planes in bf16x3 mode) in LDS in MFMA A-operand order.
+//   phase 3  the dv/16 output column fragments are split into NW contiguous ranges, one per wave: O = P V^T-rows with V^T
+//            fragments loaded straight from global memory; groups of 2-4 fragments are transposed through LDS so that the
+//            operand leaves as 16-byte stores.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bf16x8 ldg8(const frido_bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+template <int NS>
+__device__ __forceinline__ f32x4 mma(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x4 acc) {
+    if (NS == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// NW waves per workgroup (4 when the grid alone fills the chip, 8 / 16 on the small planes where only more waves per
+// workgroup shorten the serial load -> MFMA chain), NF = compile-time bound on the 16-key score fragments (Nk <= 16 NF).
+template <int NS, int NW, int NF>
+__global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmall d) {
+    constexpr int G = NW == 16 ? 2 : 4;                 // output fragments per LDS transpose group
+    constexpr int SP_LD = NF * 16 + 4, SO_LD = G * 16 + 4, P_LD = NF * 16 + 8;   // P rows: 16-byte aligned fragment reads
+    constexpr int SLD = SP_LD > SO_LD ? SP_LD : SO_LD;
+    __shared__ __attribute__((aligned(16))) float s_part[NW * 16 * SLD];          // phase 1/2 partial scores; phase 3 slabs
+    __shared__ __attribute__((aligned(16))) frido_bf16 s_p[NS * 16 * P_LD];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int z = row0 / d.Nq;
+    const int nf = (d.Nk + 15) >> 4;
+
+    // ---- phase 1: partial scores over this wave's k-steps (two k-steps of loads in flight per iteration) ----
+    {
+        f32x4 s[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const frido_bf16* qrow = d.Q + (int64_t)(row0 + r) * d.ldq + g * 8;
+        const frido_bf16* kbase = d.K + (int64_t)z * d.k_bs + g * 8;
+        int64_t koff[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            int key = j * 16 + r;
+            key = key < d.Nk ? key : d.Nk - 1;
+            koff[j] = (int64_t)key * d.ldk;
+        }
+        const int nks = d.d >> 5;
+        for (int ks = 2 * wave; ks < nks; ks += 2 * NW) {      // adjacent k-step pairs: whole 128-byte lines per row
+            const bool two = ks + 1 < nks;
+            bf16x8 a[2][2], b[2][NF][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                const int kk = (ks + u) * 32;
+                a[u][0] = ldg8(qrow + kk);
+                if (NS == 2) a[u][1] = ldg8(qrow + d.q_lo + kk);
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (j < nf) {
+                        b[u][j][0] = ldg8(kbase + koff[j] + kk);
+                        if (NS == 2) b[u][j][1] = ldg8(kbase + d.k_lo + koff[j] + kk);
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (j < nf) s[j] = mma<NS>(a[u], b[u][j], s[j]);
+            }
+        }
+        float* sp = s_part + wave * 16 * SP_LD;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            if (j < nf) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sp[(g * 4 + e) * SP_LD + j * 16 + r] = s[j][e];
+            }
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax of this wave's rows (partials summed in a fixed order: results are run-to-run identical) ----
+    const int npad = d.ldvt;
+    constexpr int RPW = 16 / NW > 0 ? 16 / NW : 1;
+    constexpr int NH = NF > 4 ? 2 : 1;                 // 64-column halves per row
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
+        if (row >= 16) break;
+        float v[NH], mx = -3.0e38f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int c = lane + h * 64;
+            v[h] = -3.0e38f;
+            if (c < d.Nk) {
+                const float* sp = s_part + row * SP_LD + c;
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc += sp[w * 16 * SP_LD];
+                v[h] = d.alpha * acc;
+            }
+            mx = fmaxf(mx, v[h]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int c = lane + h * 64;
+            v[h] = c < d.Nk ? __expf(v[h] - mx) : 0.f;
+            sum += v[h];
+        }
+        const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int c = lane + h * 64;
+            if (c < npad) {
+                uint32_t hi, lo;
+                split_bf16(v[h] * inv, hi, lo);
+                s_p[row * P_LD + c] = (frido_bf16)hi;
+                if (NS == 2) s_p[16 * P_LD + row * P_LD + c] = (frido_bf16)lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: O = P V over this wave's output column fragments ----
+    constexpr int KP = NF / 2;                          // 32-key k-steps
+    const int nkp = npad >> 5;
+    bf16x8 pa[KP][2];
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks)
+        if (ks < nkp) {
+            pa[ks][0] = *reinterpret_cast<const bf16x8*>(s_p + r * P_LD + ks * 32 + g * 8);
+            if (NS == 2) pa[ks][1] = *reinterpret_cast<const bf16x8*>(s_p + 16 * P_LD + r * P_LD + ks * 32 + g * 8);
+        }
+    // the column fragments are first split over gridDim.y workgroups (small planes: S is recomputed per split, which
+    // costs nothing next to the idle CUs), then over the waves
+    const int ntall = d.dv >> 4;
+    const int c0 = ntall * blockIdx.y / gridDim.y, nt = ntall * (blockIdx.y + 1) / gridDim.y - c0;
+    const int t0 = c0 + nt * wave / NW, t1 = c0 + nt * (wave + 1) / NW;
+    const frido_bf16* vbase = d.VT + (int64_t)z * d.vt_bs + g * 8;
+    float* so = s_part + wave * 16 * SO_LD;         // this wave's transpose slab (the partial scores are dead by now)
+    constexpr int CPL = G * 4;                      // columns per lane on the read-back: 16 rows x 4 lanes
+    const int orow = lane >> 2, oc = (lane & 3) * CPL;
+    for (int tb = t0; tb < t1; tb += G) {
+        const int ng = t1 - tb < G ? t1 - tb : G;
+        f32x4 acc[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KP; ++ks)
+            if (ks < nkp) {
+                bf16x8 b[G][2];
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (q < ng) {
+                        const frido_bf16* vr = vbase + (int64_t)((tb + q) * 16 + r) * d.ldvt + ks * 32;
+                        b[q][0] = ldg8(vr);
+                        if (NS == 2) b[q][1] = ldg8(vr + d.vt_lo);
+                    }
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (q < ng) acc[q] = mma<NS>(pa[ks], b[q], acc[q]);
+            }
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+            if (q < ng) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) so[(g * 4 + e) * SO_LD + q * 16 + r] = acc[q][e];
+            }
+        // transposed read-back: lane -> row lane/4, CPL consecutive columns, 16-byte stores
+        if (oc < ng * 16) {
+            const float* src = so + orow * SO_LD + oc;
+            frido_bf16* dst = d.out_op + (int64_t)(row0 + orow) * d.ldo + tb * 16 + oc;
+#pragma unroll
+            for (int i = 0; i < CPL / 8; ++i) {
+                uint32_t h[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split_bf16(src[i * 8 + e], h[e], l[e]);
+                *reinterpret_cast<uint4*>(dst + i * 8) =
+                    make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                if (NS == 2)
+                    *reinterpret_cast<uint4*>(dst + d.out_lo + i * 8) =
+                        make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            }
+        }
+    }
+}
+
+template <int NS>
+void launch_attn(const FridoAttnSmall& d, hipStream_t s) {
+    const int blocks = d.B * (d.Nq / 16);
+    const bool many = blocks >= 512;                    // >= 2 workgroups per CU: the grid hides the latency chain
+    const int cs = blocks >= 256 ? 1 : (blocks >= 128 ? 2 : 4);
+#define ATTN_LAUNCH(NW, NF) hipLaunchKernelGGL((attn_small_kernel<NS, NW, NF>), dim3(blocks, cs), dim3(NW * 64), 0, s, d)
+    if (d.Nk <= 32) {
+        if (many) ATTN_LAUNCH(4, 2); else ATTN_LAUNCH(16, 2);
+    } else if (d.Nk <= 64) {
+        if (many) ATTN_LAUNCH(4, 4); else ATTN_LAUNCH(8, 4);
+    } else {
+        ATTN_LAUNCH(4, 8);
+    }
+#undef ATTN_LAUNCH
+}
+
+}  // namespace
+
+extern "C" int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->Q && d->K && d->VT && d->out_op, "null pointer");
+    FRIDO_REQUIRE(d->B > 0 && d->Nq > 0 && (d->Nq & 15) == 0, "Nq must be a positive multiple of 16");
+    FRIDO_REQUIRE(d->Nk > 0 && d->Nk <= 128 && d->ldvt >= d->Nk && d->ldvt <= 128 && (d->ldvt & 31) == 0, "Nk must be in [1, 128], ldvt a multiple of 32");
+    FRIDO_REQUIRE(d->d > 0 && (d->d & 31) == 0 && d->dv > 0 && (d->dv & 15) == 0, "d must be a multiple of 32, dv of 16");
+    FRIDO_REQUIRE((d->ldq & 7) == 0 && (d->ldk & 7) == 0 && (d->ldo & 7) == 0 && (d->q_lo & 7) == 0 && (d->k_lo & 7) == 0 &&
+                      (d->vt_lo & 7) == 0 && (d->out_lo & 7) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
+                  "strides and plane offsets must keep 16-byte alignment");
+    FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
+    if (d->nsplit == 2) launch_attn<2>(*d, (hipStream_t)s);
+    else launch_attn<1>(*d, (hipStream_t)s);
+    return frido_check_launch("attn_small");
+}

@@ -53,6 +53,7 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_PLACE: return frido_place(&op.u.place, s);
         case FRIDO_OP_EMBED: return frido_embed(&op.u.embed, s);
         case FRIDO_OP_TO_U8: return frido_to_u8(&op.u.to_u8, s);
+        case FRIDO_OP_ATTN_SMALL: return frido_attn_small(&op.u.attn_small, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -228,6 +229,7 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_PLACE: return sizeof(FridoPlace);
         case FRIDO_OP_EMBED: return sizeof(FridoEmbed);
         case FRIDO_OP_TO_U8: return sizeof(FridoToU8);
+        case FRIDO_OP_ATTN_SMALL: return sizeof(FridoAttnSmall);
         default: return -1;
     }
 }

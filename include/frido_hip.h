@@ -134,6 +134,20 @@ typedef struct FridoSoftmax {
     int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
 } FridoSoftmax;
 
+/* Fused attention core for SHORT key sequences (Nk <= 128): O = softmax(alpha * Q K^T) V in one launch, the score
+ * matrix never leaving the chip.  Covers every cross-attention of the U-Net (Nk = context tokens: 26, 92 or 1) and its
+ * self-attention on the 8x8 plane (attention.py:170-193); longer sequences take the GEMM -> softmax -> GEMM path.
+ * Q rows [B*Nq] (row stride ldq), K rows [B][Nk] (per-sample stride k_bs elements, row stride ldk), VT = V transposed
+ * [B][dv][ldvt] with zero columns beyond Nk (the layout PV's B operand has on the three-kernel path), O operand rows
+ * [B*Nq] (ldo).  Nq % 16 == 0, d % 32 == 0, dv % 16 == 0, ldvt = Nk rounded up to 32. */
+typedef struct FridoAttnSmall {
+    const frido_bf16* Q; int64_t q_lo; int32_t ldq;
+    const frido_bf16* K; int64_t k_lo; int64_t k_bs; int32_t ldk;
+    const frido_bf16* VT; int64_t vt_lo; int64_t vt_bs; int32_t ldvt;
+    frido_bf16* out_op; int64_t out_lo; int32_t ldo;
+    int32_t B, Nq, Nk, d, dv, nsplit; float alpha;
+} FridoAttnSmall;
+
 /* GEGLU gate (attention.py:42-44): x[rows][2H] f32 -> operand [rows][H] = x[:, :H] * gelu_erf(x[:, H:]). */
 typedef struct FridoGeglu {
     const float* x; int32_t rows, H;
@@ -237,7 +251,7 @@ typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -247,7 +261,7 @@ typedef struct FridoOp {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8;
+        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small;
         char _size[384];
     } u;
 } FridoOp;
@@ -272,6 +286,7 @@ int frido_convt(const FridoConvT* d, frido_stream_t s);
 int frido_place(const FridoPlace* d, frido_stream_t s);
 int frido_embed(const FridoEmbed* d, frido_stream_t s);
 int frido_to_u8(const FridoToU8* d, frido_stream_t s);
+int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s);
 
 /* ---- native executor: run / capture a whole program ---- */
 int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);

@@ -271,6 +271,27 @@ def test_softmax(N):
     assert float(got[:, N:].abs().max()) == 0.0 if Np > N else True
 
 
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("B,Nq,Nk,d", [(3, 64, 26, 384), (2, 16, 1, 64), (2, 64, 64, 960), (2, 32, 92, 576), (1, 48, 128, 96),
+                                       (2, 1024, 26, 384),          # fused short-key kernel
+                                       (2, 64, 256, 64), (2, 24, 26, 64)])   # GEMM -> softmax -> GEMM path
+def test_attention_core(nsplit, B, Nq, Nk, d):
+    """softmax(q k^T / sqrt(d)) v (attention.py:170-193) for the fused short-key kernel and the three-kernel path."""
+    from frido_amd.engine import pack_matrix
+    q, k, v = _t("aq", B, Nq, d), _t("ak", B, Nk, d), _t("av", B, Nk, d)
+    b = _builder(nsplit)
+    qo = pack_matrix(q.reshape(B * Nq, d).cuda(), nsplit)
+    ko = pack_matrix(k.reshape(B * Nk, d).cuda(), nsplit)
+    vto = pack_matrix(v.transpose(1, 2).reshape(B * d, Nk).cuda(), nsplit)
+    o = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d)
+    from frido_amd import _lib
+    fused = any(kind == _lib.OP_KINDS["FRIDO_OP_ATTN_SMALL"] for kind, _ in b.prog.ops)
+    assert fused == (Nk <= 128 and Nq % 16 == 0)
+    _run(b)
+    ref = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1) @ v
+    assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < (5e-5 if nsplit == 2 else 2e-2)
+
+
 def test_geglu():
     rows, H = 33, 128
     x = _t("gx", rows, 2 * H) * 2

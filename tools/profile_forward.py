@@ -13,7 +13,11 @@ from frido_amd import _lib, configs, synth  # noqa: E402
 from bench import build_model  # noqa: E402
 
 
-def table(prog, sp, title, top=25):
+TOP = 25
+
+
+def table(prog, sp, title, top=None):
+    top = top or TOP
     prog.run(sp)
     ms = prog.run_timed(sp)
     ms2 = prog.run_timed(sp)
@@ -32,6 +36,9 @@ def table(prog, sp, title, top=25):
             desc = f"B={st.B} HW={st.HW} C={st.C1 + st.C2} S={st.nsplit_px}" + (" spade" if n == "GN_APPLY" and st.gamma else "")
         if n == "LAYERNORM":
             desc = f"rows={st.rows} C={st.C}"
+        if n == "ATTN_SMALL":
+            desc = f"B={st.B} Nq={st.Nq} Nk={st.Nk} d={st.d}"
+            fl = 4.0 * st.B * st.Nq * st.Nk * st.d
         if n == "SOFTMAX":
             desc = f"rows={st.rows} N={st.N}"
         rows.append((t, n, desc, fl))
@@ -56,7 +63,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--decode", action="store_true")
+    ap.add_argument("--top", type=int, default=25)
     a = ap.parse_args()
+    global TOP
+    TOP = a.top
     dev = torch.device("cuda:0")
     model = build_model(a.precision, dev)
     from frido_amd.samplers import DDIMSampler
