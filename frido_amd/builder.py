@@ -76,6 +76,22 @@ class Builder:
             self._wcache[key] = pack_matrix(w, self.nsplit)
         return self._wcache[key]
 
+    def folded_vo_weight(self, v_name, o_name):
+        """Single-head attention: W_o (P (X W_v^T + b_v)) + b_o = P (X (W_o W_v)^T) + (W_o b_v + b_o), because the rows of P
+        sum to one.  Returns (operand of W_o W_v, device pointer of the folded bias); the product is formed in float64."""
+        key = ("vo", v_name, o_name)
+        if key not in self._wcache:
+            wv = self.w[v_name + ".weight"].double()
+            wv = wv.reshape(wv.shape[0], -1)
+            wo = self.w[o_name + ".weight"].double()
+            wo = wo.reshape(wo.shape[0], -1)
+            bias = self.w[o_name + ".bias"].double().clone() if (o_name + ".bias") in self.w else torch.zeros(wo.shape[0], dtype=torch.float64, device=wo.device)
+            if (v_name + ".bias") in self.w:
+                bias += wo @ self.w[v_name + ".bias"].double()
+            self._wcache[key] = (pack_matrix((wo @ wv).float(), self.nsplit), bias.float().contiguous())
+        wop, bias = self._wcache[key]
+        return wop, bias.data_ptr()
+
     def cat_lin_weight(self, key, names):
         if key not in self._wcache:
             w = torch.cat([self.w[n].reshape(self.w[n].shape[0], -1) for n in names], dim=0)
@@ -269,10 +285,33 @@ class Builder:
                        d0=d0, to_nchw=int(to_nchw))
 
     # ---- attention (single head, unfused: QK^T -> softmax -> PV on the MFMA GEMM) -----------------
-    def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0):
+    def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0, bias_ptr=None, residual=None, stream=False):
         """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
-        [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158)."""
+        [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158).
+        stream=True (the out projection is folded into vT): returns the residual-stream activation O + bias + residual."""
         Np = rup(Nk, 32)
+        if stream:
+            res = self.f32(B * Nq, d)
+            if Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0:
+                self.prog.emit("FRIDO_OP_ATTN_SMALL", Q=q.ptr + 2 * q_off, q_lo=q.lo, ldq=ldq, K=k.ptr + 2 * k_off, k_lo=k.lo,
+                               k_bs=Nk * ldk, ldk=ldk, VT=vT.ptr, vt_lo=vT.lo, vt_bs=d * Np, ldvt=Np, out_act=res.ptr, ld_act=d,
+                               residual=residual.ptr if residual is not None else None, ldr=residual.C if residual is not None else 0,
+                               bias=bias_ptr, act_bf16=int(res.bf16), B=B, Nq=Nq, Nk=Nk, d=d, dv=d, nsplit=self.nsplit,
+                               alpha=float(d) ** -0.5)
+                assert residual is None or getattr(residual, "bf16", False) == res.bf16
+                return res
+            s = self.f32_strict(B * Nq, Nk)
+            self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
+                           a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)
+            p = self.softmax(s, B * Nq, Nk, Nk, Np)
+            s.free()
+            kw = {}
+            if residual is not None:
+                kw.update(residual=residual.ptr, ldr=residual.C, res_bs=Nq * residual.C, res_bf16=getattr(residual, "bf16", False))
+            self.prog.gemm(Nq, d, Np, p, vT, batch=B, lda=Np, ldb=Np, a_bs=Nq * Np, b_bs=d * Np, bias=bias_ptr, out_f32=res.ptr,
+                           of_bs=Nq * d, ldo=d, out_bf16=res.bf16, **kw)
+            p.free()
+            return res
         if Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0:
             # short key sequence: one fused launch, scores stay on chip
             o = self.op(B * Nq, d)

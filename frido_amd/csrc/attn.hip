@@ -180,20 +180,43 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
 #pragma unroll
                 for (int e = 0; e < 4; ++e) so[(g * 4 + e) * SO_LD + q * 16 + r] = acc[q][e];
             }
-        // transposed read-back: lane -> row lane/4, CPL consecutive columns, 16-byte stores
+        // transposed read-back: lane -> row lane/4, CPL consecutive columns, 16-byte accesses
         if (oc < ng * 16) {
             const float* src = so + orow * SO_LD + oc;
-            frido_bf16* dst = d.out_op + (int64_t)(row0 + orow) * d.ldo + tb * 16 + oc;
+            const int col = tb * 16 + oc;
+            if (d.out_act) {                    // residual-stream form: O + bias + residual
+                const int64_t ro = (int64_t)(row0 + orow) * d.ldr + col, oo = (int64_t)(row0 + orow) * d.ld_act + col;
 #pragma unroll
-            for (int i = 0; i < CPL / 8; ++i) {
-                uint32_t h[8], l[8];
+                for (int i = 0; i < CPL / 4; ++i) {
+                    float4 v = make_float4(src[i * 4], src[i * 4 + 1], src[i * 4 + 2], src[i * 4 + 3]);
+                    if (d.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(d.bias + col + i * 4);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    if (d.residual) {
+                        const float4 rr = load_act4(d.residual, ro + i * 4, d.act_bf16);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
+                    if (d.act_bf16) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<frido_bf16*>(d.out_act) + oo + i * 4) =
+                            make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo + i * 4) = v;
+                    }
+                }
+            } else {
+                frido_bf16* dst = d.out_op + (int64_t)(row0 + orow) * d.ldo + col;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_bf16(src[i * 8 + e], h[e], l[e]);
-                *reinterpret_cast<uint4*>(dst + i * 8) =
-                    make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-                if (NS == 2)
-                    *reinterpret_cast<uint4*>(dst + d.out_lo + i * 8) =
-                        make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+                for (int i = 0; i < CPL / 8; ++i) {
+                    uint32_t h[8], l[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) split_bf16(src[i * 8 + e], h[e], l[e]);
+                    *reinterpret_cast<uint4*>(dst + i * 8) =
+                        make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                    if (NS == 2)
+                        *reinterpret_cast<uint4*>(dst + d.out_lo + i * 8) =
+                            make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+                }
             }
         }
     }
@@ -218,7 +241,8 @@ void launch_attn(const FridoAttnSmall& d, hipStream_t s) {
 }  // namespace
 
 extern "C" int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s) {
-    FRIDO_REQUIRE(d && d->Q && d->K && d->VT && d->out_op, "null pointer");
+    FRIDO_REQUIRE(d && d->Q && d->K && d->VT && (d->out_op || d->out_act), "null pointer");
+    FRIDO_REQUIRE(!d->out_act || ((d->ld_act & 3) == 0 && (d->ldr & 3) == 0), "stream strides must be multiples of 4");
     FRIDO_REQUIRE(d->B > 0 && d->Nq > 0 && (d->Nq & 15) == 0, "Nq must be a positive multiple of 16");
     FRIDO_REQUIRE(d->Nk > 0 && d->Nk <= 128 && d->ldvt >= d->Nk && d->ldvt <= 128 && (d->ldvt & 31) == 0, "Nk must be in [1, 128], ldvt a multiple of 32");
     FRIDO_REQUIRE(d->d > 0 && (d->d & 31) == 0 && d->dv > 0 && (d->dv & 15) == 0, "d must be a multiple of 32, dv of 16");

@@ -119,8 +119,9 @@ class UNetStagePlan:
                 C = blk.cin
                 k = b.persistent_op(self.Bx * self.nctx, C, zero=False)
                 b.linear(ctx_op, t + ".to_k", bias=False, out=("op", k))
-                vT = b.v_transposed(ctx_op, a.context_dim, b.lin_weight(t + ".to_v.weight"), self.Bx, self.nctx, C)
-                self.kv[blk.prefix] = (k, vT)
+                wvo, bvo = b.folded_vo_weight(t + ".to_v", t + ".to_out.0")
+                vT = b.v_transposed(ctx_op, a.context_dim, wvo, self.Bx, self.nctx, C)
+                self.kv[blk.prefix] = (k, vT, bvo)
         ctx_op.free()
         # ---- SPADE conditioning (spade_norm.py:44-60), timestep-invariant within a stage ----
         if self.spade_on:
@@ -229,22 +230,20 @@ class UNetStagePlan:
         if (C, HW) not in self._vt_self:
             self._vt_self[(C, HW)] = b.persistent_op(C, Np, batch=Bx, zero=True)
         vT = self._vt_self[(C, HW)]
-        b.v_transposed(n1, C, b.lin_weight(t + ".attn1.to_v.weight"), Bx, HW, C, out=vT)
+        # the single-head output projection is folded into V: PV lands directly on the residual stream
+        wvo, bvo = b.folded_vo_weight(t + ".attn1.to_v", t + ".attn1.to_out.0")
+        b.v_transposed(n1, C, wvo, Bx, HW, C, out=vT)
         n1.free()
-        o = b.attention(qk, 2 * C, qk, 2 * C, vT, Bx, HW, HW, C, q_off=0, k_off=C)
+        h2 = b.attention(qk, 2 * C, qk, 2 * C, vT, Bx, HW, HW, C, q_off=0, k_off=C, bias_ptr=bvo, residual=hcur, stream=True)
         qk.free()
-        h2 = b.linear(o, t + ".attn1.to_out.0", residual=hcur)
-        o.free()
         hcur.free()
         # --- cross-attention (K, V^T cached per sample)
         n2 = b.layernorm(h2, t + ".norm2")
         q2 = b.linear(n2, t + ".attn2.to_q", bias=False, out="op")
         n2.free()
-        kc, vTc = self.kv[pre]
-        o2 = b.attention(q2, C, kc, C, vTc, Bx, HW, self.nctx, C)
+        kc, vTc, bvo2 = self.kv[pre]
+        h3 = b.attention(q2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True)
         q2.free()
-        h3 = b.linear(o2, t + ".attn2.to_out.0", residual=h2)
-        o2.free()
         h2.free()
         # --- GEGLU feed-forward (attention.py:37-64)
         n3 = b.layernorm(h3, t + ".norm3")

@@ -64,12 +64,12 @@ def vq_attn(b, B, blk_prefix, C, x, h, w):
     if vkey not in b._wcache:
         b._wcache[vkey] = b.persistent_op(C, rup(HW, 32), batch=B, zero=True)
     vT = b._wcache[vkey]
-    b.v_transposed(a0, C, b.lin_weight(pre + ".v.weight"), B, HW, C, bias_ptr=b.bias(pre + ".v.bias"), out=vT)
+    # proj_out folded into v (single head): PV + (W_o b_v + b_o) + x lands directly on the residual stream
+    wvo, bvo = b.folded_vo_weight(pre + ".v", pre + ".proj_out")
+    b.v_transposed(a0, C, wvo, B, HW, C, out=vT)
     a0.free()
-    o = b.attention(qk, 2 * C, qk, 2 * C, vT, B, HW, HW, C, q_off=0, k_off=C)
+    out = b.attention(qk, 2 * C, qk, 2 * C, vT, B, HW, HW, C, q_off=0, k_off=C, bias_ptr=bvo, residual=x, stream=True)
     qk.free()
-    out = b.linear(o, pre + ".proj_out", residual=x)
-    o.free()
     return out
 
 

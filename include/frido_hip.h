@@ -139,13 +139,17 @@ typedef struct FridoSoftmax {
  * self-attention on the 8x8 plane (attention.py:170-193); longer sequences take the GEMM -> softmax -> GEMM path.
  * Q rows [B*Nq] (row stride ldq), K rows [B][Nk] (per-sample stride k_bs elements, row stride ldk), VT = V transposed
  * [B][dv][ldvt] with zero columns beyond Nk (the layout PV's B operand has on the three-kernel path), O operand rows
- * [B*Nq] (ldo).  Nq % 16 == 0, d % 32 == 0, dv % 16 == 0, ldvt = Nk rounded up to 32. */
+ * [B*Nq] (ldo).  Nq % 16 == 0, d % 32 == 0, dv % 16 == 0, ldvt = Nk rounded up to 32.
+ * With `out_act` set the result leaves as the residual stream instead of an operand:
+ * out_act[row][c] = O[row][c] + bias[c] + residual[row][c] (f32, or bf16 when act_bf16) -- the form used when the
+ * attention output projection has been folded into V (single head: W_o (P V) = P (V W_o^T)). */
 typedef struct FridoAttnSmall {
     const frido_bf16* Q; int64_t q_lo; int32_t ldq;
     const frido_bf16* K; int64_t k_lo; int64_t k_bs; int32_t ldk;
     const frido_bf16* VT; int64_t vt_lo; int64_t vt_bs; int32_t ldvt;
     frido_bf16* out_op; int64_t out_lo; int32_t ldo;
     int32_t B, Nq, Nk, d, dv, nsplit; float alpha;
+    void* out_act; const void* residual; const float* bias; int32_t ld_act, ldr, act_bf16;
 } FridoAttnSmall;
 
 /* GEGLU gate (attention.py:42-44): x[rows][2H] f32 -> operand [rows][H] = x[:, :H] * gelu_erf(x[:, H:]). */

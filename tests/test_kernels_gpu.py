@@ -292,6 +292,27 @@ def test_attention_core(nsplit, B, Nq, Nk, d):
     assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < (5e-5 if nsplit == 2 else 2e-2)
 
 
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("B,Nq,Nk,d", [(2, 64, 26, 384), (2, 64, 64, 960), (2, 256, 256, 64)])
+def test_attention_core_stream_output(nsplit, B, Nq, Nk, d):
+    """Residual-stream form used when the output projection is folded into V: softmax(qk^T/sqrt(d)) v + bias + residual."""
+    from frido_amd.engine import pack_matrix
+    q, k, v = _t("aq", B, Nq, d), _t("ak", B, Nk, d), _t("av", B, Nk, d)
+    bias, res = _t("ab", d), _t("ar", B * Nq, d)
+    b = _builder(nsplit)
+    qo = pack_matrix(q.reshape(B * Nq, d).cuda(), nsplit)
+    ko = pack_matrix(k.reshape(B * Nk, d).cuda(), nsplit)
+    vto = pack_matrix(v.transpose(1, 2).reshape(B * d, Nk).cuda(), nsplit)
+    bd = bias.cuda()
+    r = b.f32(B * Nq, d)
+    r.view().copy_(res.cuda())
+    o = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d, bias_ptr=bd.data_ptr(), residual=r, stream=True)
+    _run(b)
+    rq = r.to_f32().cpu()       # the residual as stored (bf16-rounded in bf16 mode)
+    ref = (torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1) @ v).reshape(B * Nq, d) + bias + rq
+    assert _relerr(o.to_f32().cpu(), ref) < (5e-5 if nsplit == 2 else 2e-2)
+
+
 def test_geglu():
     rows, H = 33, 128
     x = _t("gx", rows, 2 * H) * 2
