@@ -92,6 +92,27 @@ class Builder:
         wop, bias = self._wcache[key]
         return wop, bias.data_ptr()
 
+    def folded_qk_weight(self, q_name, k_name, side):
+        """Single-head scores S = (x W_q^T + b_q)(y W_k^T + b_k)^T.  Terms constant along the key axis cancel in the softmax,
+        so S ~ x (W_q^T W_k) y^T + (W_k^T b_q) . y.  side="q": returns W' = W_k^T W_q and b' = W_k^T b_q with
+        S = (x W'^T + b') y^T (the keys are the raw input rows);  side="k": returns W'' = W_q^T W_k with S = x (y W''^T)^T
+        (only valid without a query bias: the projected keys can be cached and the queries are the raw input rows)."""
+        key = ("qk", q_name, k_name, side)
+        if key not in self._wcache:
+            wq = self.w[q_name + ".weight"].double()
+            wq = wq.reshape(wq.shape[0], -1)
+            wk = self.w[k_name + ".weight"].double()
+            wk = wk.reshape(wk.shape[0], -1)
+            bq = self.w[q_name + ".bias"].double() if (q_name + ".bias") in self.w else None
+            if side == "q":
+                bias = (wk.t() @ bq).float().contiguous() if bq is not None else None
+                self._wcache[key] = (pack_matrix((wk.t() @ wq).float(), self.nsplit), bias)
+            else:
+                assert bq is None, "a query bias cannot be folded into the key side"
+                self._wcache[key] = (pack_matrix((wq.t() @ wk).float(), self.nsplit), None)
+        wop, bias = self._wcache[key]
+        return wop, (bias.data_ptr() if bias is not None else None)
+
     def cat_lin_weight(self, key, names):
         if key not in self._wcache:
             w = torch.cat([self.w[n].reshape(self.w[n].shape[0], -1) for n in names], dim=0)

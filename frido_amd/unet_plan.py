@@ -118,7 +118,8 @@ class UNetStagePlan:
                 t = f"{blk.prefix}.transformer_blocks.0.attn2"
                 C = blk.cin
                 k = b.persistent_op(self.Bx * self.nctx, C, zero=False)
-                b.linear(ctx_op, t + ".to_k", bias=False, out=("op", k))
+                wkq, _ = b.folded_qk_weight(t + ".to_q", t + ".to_k", "k")
+                b.linear(ctx_op, None, wop=wkq, bias=False, out=("op", k))
                 wvo, bvo = b.folded_vo_weight(t + ".to_v", t + ".to_out.0")
                 vT = b.v_transposed(ctx_op, a.context_dim, wvo, self.Bx, self.nctx, C)
                 self.kv[blk.prefix] = (k, vT, bvo)
@@ -223,9 +224,9 @@ class UNetStagePlan:
         a0.free()
         # --- self-attention
         n1 = b.layernorm(hcur, t + ".norm1")
-        wqk = b.cat_lin_weight(("qk", t), [t + ".attn1.to_q.weight", t + ".attn1.to_k.weight"])
-        qk = b.op(Bx * HW, 2 * C)
-        b.linear(n1, None, wop=wqk, bias=False, out=("op", qk))
+        # scores: q' = n1 (W_q^T W_k) against the raw rows of n1 (the key projection is folded into the query side)
+        wq, _ = b.folded_qk_weight(t + ".attn1.to_q", t + ".attn1.to_k", "q")
+        qp = b.linear(n1, None, wop=wq, bias=False, out="op")
         Np = rup(HW, 32)
         if (C, HW) not in self._vt_self:
             self._vt_self[(C, HW)] = b.persistent_op(C, Np, batch=Bx, zero=True)
@@ -233,17 +234,15 @@ class UNetStagePlan:
         # the single-head output projection is folded into V: PV lands directly on the residual stream
         wvo, bvo = b.folded_vo_weight(t + ".attn1.to_v", t + ".attn1.to_out.0")
         b.v_transposed(n1, C, wvo, Bx, HW, C, out=vT)
+        h2 = b.attention(qp, C, n1, C, vT, Bx, HW, HW, C, bias_ptr=bvo, residual=hcur, stream=True)
+        qp.free()
         n1.free()
-        h2 = b.attention(qk, 2 * C, qk, 2 * C, vT, Bx, HW, HW, C, q_off=0, k_off=C, bias_ptr=bvo, residual=hcur, stream=True)
-        qk.free()
         hcur.free()
         # --- cross-attention (K, V^T cached per sample)
         n2 = b.layernorm(h2, t + ".norm2")
-        q2 = b.linear(n2, t + ".attn2.to_q", bias=False, out="op")
+        kc, vTc, bvo2 = self.kv[pre]            # kc = ctx (W_q^T W_k)^T: the query projection is folded into the cached keys
+        h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True)
         n2.free()
-        kc, vTc, bvo2 = self.kv[pre]
-        h3 = b.attention(q2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True)
-        q2.free()
         h2.free()
         # --- GEGLU feed-forward (attention.py:37-64)
         n3 = b.layernorm(h3, t + ".norm3")

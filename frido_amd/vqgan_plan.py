@@ -54,12 +54,9 @@ def vq_attn(b, B, blk_prefix, C, x, h, w):
     HW = h * w
     pre = blk_prefix
     a0, _ = b.groupnorm(x, None, B, HW, pre + ".norm", 1e-6, act=ACT_NONE)
-    wqk = b.cat_lin_weight(("vqk", pre), [pre + ".q.weight", pre + ".k.weight"])
-    key = ("vqk_bias", pre)
-    if key not in b._wcache:
-        b._wcache[key] = torch.cat([b.w[pre + ".q.bias"].float(), b.w[pre + ".k.bias"].float()]).contiguous()
-    qk = b.op(B * HW, 2 * C)
-    b.linear(a0, None, wop=wqk, bias_ptr=b._wcache[key].data_ptr(), out=("op", qk))
+    # scores: q' = a0 (W_q^T W_k) + W_k^T b_q against the raw rows of a0 (key-side bias terms cancel in the softmax)
+    wq, bq = b.folded_qk_weight(pre + ".q", pre + ".k", "q")
+    qp = b.linear(a0, None, wop=wq, bias_ptr=bq, bias=False, out="op")
     vkey = ("vT", C, HW, B)
     if vkey not in b._wcache:
         b._wcache[vkey] = b.persistent_op(C, rup(HW, 32), batch=B, zero=True)
@@ -67,9 +64,9 @@ def vq_attn(b, B, blk_prefix, C, x, h, w):
     # proj_out folded into v (single head): PV + (W_o b_v + b_o) + x lands directly on the residual stream
     wvo, bvo = b.folded_vo_weight(pre + ".v", pre + ".proj_out")
     b.v_transposed(a0, C, wvo, B, HW, C, out=vT)
+    out = b.attention(qp, C, a0, C, vT, B, HW, HW, C, bias_ptr=bvo, residual=x, stream=True)
+    qp.free()
     a0.free()
-    out = b.attention(qk, 2 * C, qk, 2 * C, vT, B, HW, HW, C, q_off=0, k_off=C, bias_ptr=bvo, residual=x, stream=True)
-    qk.free()
     return out
 
 
