@@ -92,6 +92,28 @@ class Builder:
         wop, bias = self._wcache[key]
         return wop, bias.data_ptr()
 
+    def chained_linear(self, a, a2, first, second, residual):
+        """y = second(first(a) + a2) + residual with both Linears in ONE GEMM: [a | a2] . [W_s W_f | W_s]^T + (W_s b_f + b_s).
+        bf16-stream mode only (a2 is a bf16 activation read as a second A operand along K)."""
+        key = ("chain", first, second)
+        if key not in self._wcache:
+            wf, ws = self.w[first + ".weight"].double(), self.w[second + ".weight"].double()
+            wf, ws = wf.reshape(wf.shape[0], -1), ws.reshape(ws.shape[0], -1)
+            bias = ws @ self.w[first + ".bias"].double() + self.w[second + ".bias"].double()
+            k1, k2 = rup(wf.shape[1], 64), rup(ws.shape[1], 64)
+            w = torch.zeros((ws.shape[0], k1 + k2), dtype=torch.float64, device=ws.device)
+            w[:, :wf.shape[1]] = ws @ wf
+            w[:, k1:k1 + ws.shape[1]] = ws
+            self._wcache[key] = (pack_matrix(w.float(), self.nsplit), bias.float().contiguous(), k1, k2)
+        wop, bias, k1, k2 = self._wcache[key]
+        assert getattr(a2, "bf16", False) and a.K == k1 and a2.C == k2, (a.K, k1, a2.C, k2)
+        M = a.rows * getattr(a, "batch", 1)
+        res = self.f32(M, wop.rows)
+        self.prog.gemm(M, wop.rows, k1, a, wop, ldb=k1 + k2, bias=bias.data_ptr(), residual=residual.ptr, ldr=residual.C,
+                       res_bf16=getattr(residual, "bf16", False), out_f32=res.ptr, ldo=wop.rows, out_bf16=res.bf16,
+                       A2=a2, lda2=a2.C, K2=k2)
+        return res
+
     def folded_qk_weight(self, q_name, k_name, side):
         """Single-head scores S = (x W_q^T + b_q)(y W_k^T + b_k)^T.  Terms constant along the key axis cancel in the softmax,
         so S ~ x (W_q^T W_k) y^T + (W_k^T b_q) . y.  side="q": returns W' = W_k^T W_q and b' = W_k^T b_q with

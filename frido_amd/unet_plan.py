@@ -248,6 +248,12 @@ class UNetStagePlan:
         n3 = b.layernorm(h3, t + ".norm3")
         gg = b.linear_geglu(n3, t + ".ff.net.0.proj")
         n3.free()
+        if b.stream_bf16 and C % 64 == 0:
+            # proj_out(h3 + ff2(gg)) + x in one GEMM: ff2 and proj_out are both linear, h3 rides along as a second K range
+            out = b.chained_linear(gg, h3, t + ".ff.net.2", pre + ".proj_out", x)
+            gg.free()
+            h3.free()
+            return out
         h4 = b.linear(gg, t + ".ff.net.2", residual=h3, out="op")
         gg.free()
         h3.free()

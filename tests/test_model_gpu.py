@@ -75,6 +75,18 @@ def test_unet_full_width_forward_matches_reference_golden():
         assert _rel(e, g[f"eps_{s}"]) < 2e-4, s
 
 
+def test_unet_full_width_bf16_mode_within_bf16_tolerance():
+    """The benchmark's arithmetic (single bf16 plane, bf16 residual stream, chained FF2+proj_out GEMM) at the full
+    layout2i width against the reference golden."""
+    g = golden("unet_full")
+    from frido_amd.models import PyUNetModel
+    m = fill_module(PyUNetModel(**UNET_FULL, precision="bf16"), "model.diffusion_model.").cuda()
+    x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    for s in range(2):
+        e = m(x[:, :3 * (s + 1)].contiguous(), torch.from_numpy(g[f"t_{s}"]).cuda(), context=ctx, stage=s)
+        assert _rel(e, g[f"eps_{s}"]) < 5e-2, s
+
+
 def test_no_cpu_fallback():
     from frido_amd.models import PyUNetModel
     from frido_amd._lib import FridoHipError
