@@ -70,6 +70,181 @@ __device__ __forceinline__ void wait_tail(int rem) {
     }
 }
 
+// ---- epilogue (shared by the ring kernel and the patch-staged 3x3 kernel) --------------------------------------
+template <int BM, int BN, int NS, int WM>
+__device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[BM / WM / 16][BN / 2 / 16], unsigned char* smem,
+                                              int m0, int n0, int wave, int lane, int zo, int zi, int kz) {
+    constexpr int WN = 2, TM = BM / WM / 16, TN = BN / WN / 16;
+    const int wm = wave >> 1, wn = wave & 1;
+    // MFMA leaves lane l with D[row = (l>>4)*4 + e][col = l & 15] of each 16x16 tile (16 lanes x 4 B per row segment).
+    // Each 16-row slab of the wave's sub-tile is transposed through the (now idle) LDS ring so that every lane owns 8
+    // CONSECUTIVE columns of one row: bias / timestep vector / residual come in as 16-byte loads and the results leave
+    // as 16-byte stores (store ISSUE, not bandwidth, bounds this phase: 8-byte stores measured 2x slower).
+    constexpr int WR = BM / WM, WC = BN / WN, EPS = WC + 4;          // +4 floats: conflict-free slab writes
+    constexpr int LPR8 = WC / 8, RPP8 = 64 / LPR8;                    // lanes per row (8 columns each), rows per pass
+    if (d.act == 99) {      // profiling aid (tools/gemm_bench.py NOEPI=1): keep the accumulators live, store nothing
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sink == 1.2345e-30f) d.out_f32[0] = sink;
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                                      // every wave is done reading the ring
+    if (d.act == 96) { if (acc[0][0][0] == 1.2345e-30f) d.out_f32[0] = acc[0][0][1]; return; }
+    float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EPS);
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const int er8 = lane / LPR8, ec8 = (lane - er8 * LPR8) * 8;        // this lane's (row, first column) in a pass
+    const bool lane_on8 = lane < RPP8 * LPR8;
+    int vstep = 0;
+    if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
+    const int nbase = n0 + wn * WC;
+    // vector path (8 columns per lane: 16-byte bf16 / 2 x 16-byte f32 accesses) needs 8-element aligned rows and planes
+    const bool vec_ok = gridDim.z > 1 ? (d.N & 3) == 0
+                                      : ((d.ldo | d.ldr | d.ldoo | d.ldv | d.N | d.of_bs | d.of_bs2 | d.oo_bs | d.oo_bs2 | d.res_bs | d.oo_lo) & 7) == 0;
+    const int64_t of_base = (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2;
+    const int64_t oo_base = (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2;
+    const int64_t rs_base = (int64_t)zo * d.res_bs;
+    float* wsp = gridDim.z > 1 ? d.ws + (int64_t)kz * d.M * d.N : nullptr;
+    constexpr int NP = (16 + RPP8 - 1) / RPP8;                         // passes per 16-row slab
+    // per-lane invariants: this lane's 8 columns are the same in every pass of every slab
+    const int ncol = nbase + ec8;
+    const bool fast = vec_ok && (d.N & 7) == 0;        // every lane's 8 columns are then all inside or all outside N
+    float bia[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bia[e] = 0.f;
+    if (fast && d.bias && !wsp && !d.geglu && lane_on8 && ncol < d.N) {
+        const float4 t0 = *reinterpret_cast<const float4*>(d.bias + ncol), t1 = *reinterpret_cast<const float4*>(d.bias + ncol + 4);
+        bia[0] = t0.x; bia[1] = t0.y; bia[2] = t0.z; bia[3] = t0.w; bia[4] = t1.x; bia[5] = t1.y; bia[6] = t1.z; bia[7] = t1.w;
+    }
+    for (int i = 0; i < TM; ++i) {
+        // static accumulator indices only: if the compiler keeps this (large) loop rolled, acc[i] with a dynamic i would
+        // move the whole accumulator tile to scratch
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+            if (ii == i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = acc[ii][j][e];
+            }
+        if (d.geglu) {       // 16-column blocks alternate [a | gate] (attention.py:42-44): every lane makes 4 outputs
+            constexpr int LPRG = WC / 8, RPPG = 64 / LPRG;
+            const int gr = lane / LPRG, gc = (lane - gr * LPRG) * 4;          // row, first OUTPUT column of this lane
+            const int ac = (gc >> 4) * 32 + (gc & 15);                        // column of `a` inside the wave's slab
+            for (int ps = 0; ps < 16; ps += RPPG) {
+                const int r = ps + gr;
+                const int m = m0 + wm * WR + i * 16 + r;
+                const int n = nbase + ac;
+                if (lane >= RPPG * LPRG || r >= 16 || m >= d.M || n + 16 >= d.N) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac);
+                const float4 g4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac + 16);
+                float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+                if (d.bias) { ba = *reinterpret_cast<const float4*>(d.bias + n); bg = *reinterpret_cast<const float4*>(d.bias + n + 16); }
+                const float o[4] = {(a4.x * d.alpha + ba.x) * gelu_f(g4.x * d.alpha + bg.x), (a4.y * d.alpha + ba.y) * gelu_f(g4.y * d.alpha + bg.y),
+                                    (a4.z * d.alpha + ba.z) * gelu_f(g4.z * d.alpha + bg.z), (a4.w * d.alpha + ba.w) * gelu_f(g4.w * d.alpha + bg.w)};
+                store_op4(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + (n >> 5) * 16 + (n & 15), o);
+            }
+            continue;
+        }
+        if (!fast) {
+            // generic element-wise path (ragged N or unaligned strides: the 3-channel output conv, odd test shapes).  Rolled
+            // and scalar on purpose: unrolled per-element fallbacks inside the vector path tripled the kernel's code size.
+#pragma unroll 1
+            for (int idx = lane; idx < 16 * WC; idx += 64) {
+                const int r = idx / WC, c = idx - r * WC;
+                const int m = m0 + wm * WR + i * 16 + r, n = nbase + c;
+                if (m >= d.M || n >= d.N) continue;
+                float x = ep[r * EPS + c];
+                if (wsp) { wsp[(int64_t)m * d.N + n] = x; continue; }
+                x = x * d.alpha + (d.bias ? d.bias[n] : 0.f) + (d.row_bias ? d.row_bias[m] : 0.f);
+                if (d.rowvec) x += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
+                if (d.act == FRIDO_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (d.act == FRIDO_ACT_SILU) x = silu_f(x);
+                else if (d.act == FRIDO_ACT_GELU) x = gelu_f(x);
+                if (d.residual) x += load_act1(d.residual, rs_base + (int64_t)m * d.ldr + n, d.res_bf16);
+                if (d.out_f32) store_act1(d.out_f32, of_base + (int64_t)m * d.ldo + n, d.out_bf16, x);
+                if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, x);
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int p = 0; p < NP; ++p) {
+            const int r = p * RPP8 + er8;
+            const int m = m0 + wm * WR + i * 16 + r, n = ncol;
+            if (!lane_on8 || r >= 16 || m >= d.M || n >= d.N) continue;
+            float v[8];
+            {
+                const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ec8);
+                const float4 b4 = *reinterpret_cast<const float4*>(ep + r * EPS + ec8 + 4);
+                v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+            }
+            if (wsp) {                       // split-K: raw partial sums; splitk_reduce_kernel applies the epilogue
+                float* w = wsp + (int64_t)m * d.N + n;
+                *reinterpret_cast<float4*>(w) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(w + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                continue;
+            }
+            float rb = d.row_bias ? d.row_bias[m] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + bia[e] + rb;
+            if (d.rowvec) {
+                const float* rp = d.rowvec + (int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n;
+                const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+            }
+            // the activation switch stays OUTSIDE the element loops (inside, hipcc if-converts it and evaluates expf and the
+            // erff polynomial for every element of every GEMM)
+            if (d.act == FRIDO_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (d.act == FRIDO_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            } else if (d.act == FRIDO_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            }
+            if (d.residual) {
+                const int64_t ro = rs_base + (int64_t)m * d.ldr + n;
+                if (d.res_bf16) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const frido_bf16*>(d.residual) + ro);
+                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                    v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                    v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                } else {
+                    const float* rp = reinterpret_cast<const float*>(d.residual) + ro;
+                    const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                }
+            }
+            if (d.act == 98) { if (v[0] == 1.2345e-30f) d.out_f32[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; continue; }
+            if (d.out_f32) {
+                const int64_t o = of_base + (int64_t)m * d.ldo + n;
+                if (d.out_bf16) {
+                    *reinterpret_cast<uint4*>(reinterpret_cast<frido_bf16*>(d.out_f32) + o) =
+                        make_uint4(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16),
+                                   f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16), f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16));
+                } else {
+                    *reinterpret_cast<float4*>(d.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(d.out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            if (d.out_op) {
+                uint32_t h[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+                frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + n;
+                *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                if (d.nsplit == 2)
+                    *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int NS, bool CONV, int BK>
 __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW == 8 ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
     using G = Geo<BM, BN, NS, BK>;
@@ -301,118 +476,222 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         buf = buf + 1 == D ? 0 : buf + 1;
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------------
-    // MFMA leaves lane l with D[row = (l>>4)*4 + e][col = l & 15] of each 16x16 tile (16 lanes x 4 B per row segment).
-    // Each 16-row slab of the wave's sub-tile is transposed through the (now idle) LDS ring so that every lane owns 4
-    // CONSECUTIVE columns of one row: bias / timestep vector / residual come in as 16-byte loads and the results leave
-    // as 8- or 16-byte stores (the per-element form was 15-40 % of the kernel on the U-Net shapes).
-    constexpr int WR = BM / WM, WC = BN / WN, EPS = WC + 4;          // +4 floats: conflict-free slab writes
-    constexpr int LPR = WC / 4, RPP = 64 / LPR;                       // lanes per row, rows per pass
-    if (d.act == 99) {      // profiling aid (tools/gemm_bench.py NOEPI=1): keep the accumulators live, store nothing
-        float sink = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sink == 1.2345e-30f) d.out_f32[0] = sink;
-        return;
+    tile_epilogue<BM, BN, NS, WM>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz);
+}
+
+// =====================================================================================================================
+// Patch-staged 3x3 convolution (stride 1, pad 1, no resampling), bf16 mode, 256 x 192 tile, 8 waves.
+//
+// The ring kernel above re-fetches every input pixel once per tap (9x) and is bound by the ~20 B/clk/CU L2 -> LDS DMA rate
+// (PMC: 37 % of wave time parked on vmcnt at 10 TB/s aggregate).  Here the 256 output pixels of a tile are R complete image
+// rows (or 256 / HW whole small images), so their receptive field is a (R+2) x (W+2) pixel PATCH per 32-channel chunk: it is
+// DMA'd into LDS ONCE (zero halo from the zero page) and serves all nine taps -- a tap is a constant LDS row shift of the A
+// fragment address.  Only the weights stream per tap.  DMA bytes per FLOP drop ~2x vs the 256-row ring tile, ~3.5x vs 128 x 192.
+//
+//   LDS: 2 patch buffers x 32 KiB (512 pixel slots x 64 B) + DB weight stages x 12 KiB ([192][32] bf16).
+//   Patch slot s holds its four 16-byte k-pieces at q ^ (((s >> 2) & 1) << 1): with the ds_read_b128 lane groups of gfx950
+//   ({0-3,12-15 | 20-27} ...) sixteen CONSECUTIVE slots are conflict-free from ANY starting slot, which the tap shifts need.
+//   k-walk: for every 32-channel chunk: 9 taps; then the chunks of the optional second operand A2 (fused 1x1 skip conv,
+//   centre tap only).  vmcnt: loads retire in order, so "stage landed" = at most (pieces issued after it) outstanding; the
+//   per-wave issue counter and the marks of the DB-1 youngest weight stages / two patches live in SGPRs.
+template <int BN>
+struct PGeo {
+    static constexpr int BM = 256, NW = 8, NT = 512, WM = 4;
+    static constexpr int PBUF = 32 * 1024, BSTAGE = BN * 64, DB = 6;
+    static constexpr int B0 = 2 * PBUF;
+    static constexpr int EPI = NW * 16 * (BN / 2 + 4) * 4;
+    static constexpr int SMEM = B0 + DB * BSTAGE > EPI ? B0 + DB * BSTAGE : EPI;
+    static_assert(BN == 192, "weight-stage DMA split assumes 12 chunks: 8 + 4");
+    static_assert(SMEM <= 163840, "LDS budget");
+};
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n = loads that may stay in flight (uniform); rounding down is safe
+    switch (n) {
+#define W_(N) case N: wait_vmcnt<N>(); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16)
+        W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31) W_(32)
+#undef W_
+        default: wait_vmcnt<32>(); break;
     }
-    __builtin_amdgcn_s_barrier();                                      // every wave is done reading the ring
-    float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EPS);
-    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-    const int er = lane / LPR, ec = (lane - er * LPR) * 4;             // this lane's (row, first column) in a pass
-    const bool lane_on = lane < RPP * LPR;
-    int vstep = 0;
-    if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
-    const int nbase = n0 + wn * WC;
-    // vector path needs 16-byte (f32) / 8-byte (bf16) aligned rows
-    const bool vec_ok = ((d.ldo | d.ldr | d.ldoo | d.ldv | d.N) & 3) == 0 || (gridDim.z > 1 && (d.N & 3) == 0);
-    const int64_t of_base = (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2;
-    const int64_t oo_base = (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2;
-    const int64_t rs_base = (int64_t)zo * d.res_bs;
-    float* wsp = gridDim.z > 1 ? d.ws + (int64_t)kz * d.M * d.N : nullptr;
+}
+
+template <int BN>
+__global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d) {
+    using P = PGeo<BN>;
+    constexpr int BM = P::BM, NW = P::NW, WM = P::WM, TM = BM / WM / 16, TN = BN / 2 / 16, DB = P::DB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int nb = (d.M / BM) * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- tile geometry ----
+    const int W = d.Ws, H = d.Hs, HW = H * W;
+    const int RW = HW < BM ? HW : BM;          // output pixels per group (one group = R rows of one image)
+    const int R = RW / W, PW = W + 2, PS = (R + 2) * PW;
+    const int ngrp = BM / RW;
+    const int img0 = m0 / HW, y0 = (m0 - img0 * HW) / W;
+
+    // ---- patch DMA pieces of this lane: chunks wave, wave+8, wave+16, wave+24; slot = chunk*16 + lane/4 ----
+    const int pq = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 8;      // logical k-piece this lane fetches (elements)
+    int pix[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = (wave + 8 * j) * 16 + (lane >> 2);
+        const int g = slot / PS, rem = slot - g * PS;
+        const int pr = rem / PW, px = rem - pr * PW;
+        const int y = y0 + pr - 1, x = px - 1;
+        const bool ok = g < ngrp && y >= 0 && y < H && x >= 0 && x < W;
+        pix[j] = ok ? (img0 + g) * HW + y * W + x : -1;
+    }
+    // ---- weight DMA pieces: chunk `wave` (all waves) and chunk 8 + wave (waves 0-3); existing BK = 32 row swizzle ----
+    const int lrow = lane >> 2;
+    const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
+    const int lpb = wave < 4 ? 2 : 1;
+    int64_t b_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int n = n0 + (wave + 8 * j) * 16 + lrow;
+        n = n < d.N ? n : d.N - 1;
+        b_off[j] = (int64_t)n * d.ldb + lq * 8;
+    }
+    const frido_bf16* __restrict__ Ab = d.A;
+    const frido_bf16* __restrict__ A2b = d.A2;
+    const frido_bf16* __restrict__ Bb = d.B;
+    const int cin = d.Cin;
+    const int nc1 = cin >> 5, nc2 = d.K2 >> 5, nch = nc1 + nc2;
+    const int S = 9 * nc1 + nc2;
+    unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
+    asm volatile("" : "+s"(zero_addr));
+
+    auto issue_patch = [&](int c, int pb) {
+        const frido_bf16* base;
+        int64_t ld;
+        if (c < nc1) { base = Ab + c * 32 + pq; ld = cin; }
+        else { base = A2b + (c - nc1) * 32 + pq; ld = d.lda2; }
+        unsigned char* dst = smem + pb * P::PBUF + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const frido_bf16* src = pix[j] >= 0 ? base + (int64_t)pix[j] * ld : reinterpret_cast<const frido_bf16*>(zero_addr);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 8192), 16, 0, 0);
+        }
+    };
+    // issue-side k-walk (uniform): chunk / tap of the next weight stage to fetch
+    int ic = 0, it = nc1 > 0 ? 0 : 4;
+    auto issue_b = [&](int stage) {
+        const int64_t koff = ic < nc1 ? (int64_t)it * cin + ic * 32 : (int64_t)d.K + (ic - nc1) * 32;
+        unsigned char* dst = smem + P::B0 + stage * P::BSTAGE + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bb + b_off[0] + koff), (lptr_t)dst, 16, 0, 0);
+        if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)(Bb + b_off[1] + koff), (lptr_t)(dst + 8192), 16, 0, 0);
+        if (ic < nc1 && it < 8) ++it;
+        else { ++ic; it = ic < nc1 ? 0 : 4; }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing ----
+    const int frow = lane & 15, kg = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    int sbase[TM];                                                    // patch slot of this lane's output pixel (centre tap)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int ml = wm * (BM / WM) + i * 16 + frow;
+        const int g = ml / RW, rem = ml - g * RW;
+        const int r = rem / W, x = rem - r * W;
+        sbase[i] = g * PS + (r + 1) * PW + (x + 1);
+    }
+    const unsigned b_frag = lds0 + P::B0 + (wn * (BN / 2) + frow) * 64 + ((kg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
+
+    // ---- prologue ----
+    int tot = 0;                      // DMA pieces this wave has issued
+    issue_patch(0, 0);
+    tot += 4;
+    int markp_cur = tot, markp_nxt = tot;      // issue count right after the current / next chunk's patch
+    int mark[DB - 1];                          // ... right after the weight stages of steps s .. s+DB-2
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = acc[i][j][e];
-        if (d.geglu) {       // 16-column blocks alternate [a | gate] (attention.py:42-44): every lane makes 4 outputs
-            constexpr int LPRG = WC / 8, RPPG = 64 / LPRG;
-            const int gr = lane / LPRG, gc = (lane - gr * LPRG) * 4;          // row, first OUTPUT column of this lane
-            const int ac = (gc >> 4) * 32 + (gc & 15);                        // column of `a` inside the wave's slab
-            for (int ps = 0; ps < 16; ps += RPPG) {
-                const int r = ps + gr;
-                const int m = m0 + wm * WR + i * 16 + r;
-                const int n = nbase + ac;
-                if (lane >= RPPG * LPRG || r >= 16 || m >= d.M || n + 16 >= d.N) continue;
-                const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac);
-                const float4 g4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac + 16);
-                float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-                if (d.bias) { ba = *reinterpret_cast<const float4*>(d.bias + n); bg = *reinterpret_cast<const float4*>(d.bias + n + 16); }
-                const float o[4] = {(a4.x * d.alpha + ba.x) * gelu_f(g4.x * d.alpha + bg.x), (a4.y * d.alpha + ba.y) * gelu_f(g4.y * d.alpha + bg.y),
-                                    (a4.z * d.alpha + ba.z) * gelu_f(g4.z * d.alpha + bg.z), (a4.w * d.alpha + ba.w) * gelu_f(g4.w * d.alpha + bg.w)};
-                store_op4(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + (n >> 5) * 16 + (n & 15), o);
-            }
-            continue;
+    for (int s = 0; s < DB - 1; ++s) {
+        if (s < S) { issue_b(s); tot += lpb; }
+        mark[s] = tot;
+    }
+
+    int cc = 0, tc = nc1 > 0 ? 0 : 4;          // compute-side k-walk
+    int stage = 0;
+    bool first = true;                         // first step of chunk cc
+    for (int s = 0; s < S; ++s) {
+        {
+            const int need = mark[0] > markp_cur ? mark[0] : markp_cur;
+            wait_vmcnt_dyn(tot - need);
         }
-        for (int ps = 0; ps < 16; ps += RPP) {
-            const int r = ps + er;
-            if (!lane_on || r >= 16) continue;
-            const int m = m0 + wm * WR + i * 16 + r;
-            const int n = nbase + ec;
-            if (m >= d.M || n >= d.N) continue;
-            const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ec);
-            float v[4] = {a4.x, a4.y, a4.z, a4.w};
-            const bool full = vec_ok && n + 3 < d.N;
-            if (wsp) {                       // split-K: raw partial sums; splitk_reduce_kernel applies the epilogue
-                if (full) *reinterpret_cast<float4*>(wsp + (int64_t)m * d.N + n) = a4;
-                else for (int e = 0; e < 4 && n + e < d.N; ++e) wsp[(int64_t)m * d.N + n + e] = v[e];
-                continue;
+        __builtin_amdgcn_s_barrier();          // stage s (and patch cc) visible to every wave; stage s-1 / patch cc-1 are free
+        int newmark;
+        {
+            if (s + DB - 1 < S) {
+                int st = stage + DB - 1;
+                st = st >= DB ? st - DB : st;
+                issue_b(st);
+                tot += lpb;
             }
-            const int nv = full ? 4 : min(4, d.N - n);
-            float bia[4] = {0.f, 0.f, 0.f, 0.f}, rvv[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
-            const int64_t rv_off = d.rowvec ? (int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n : 0;
-            if (full) {
-                if (d.bias) { const float4 t4 = *reinterpret_cast<const float4*>(d.bias + n); bia[0] = t4.x; bia[1] = t4.y; bia[2] = t4.z; bia[3] = t4.w; }
-                if (d.rowvec) { const float4 t4 = *reinterpret_cast<const float4*>(d.rowvec + rv_off); rvv[0] = t4.x; rvv[1] = t4.y; rvv[2] = t4.z; rvv[3] = t4.w; }
-                if (d.residual) { const float4 t4 = load_act4(d.residual, rs_base + (int64_t)m * d.ldr + n, d.res_bf16); res[0] = t4.x; res[1] = t4.y; res[2] = t4.z; res[3] = t4.w; }
-            } else {
-                for (int e = 0; e < nv; ++e) {
-                    if (d.bias) bia[e] = d.bias[n + e];
-                    if (d.rowvec) rvv[e] = d.rowvec[rv_off + e];
-                    if (d.residual) res[e] = load_act1(d.residual, rs_base + (int64_t)m * d.ldr + n + e, d.res_bf16);
-                }
+            newmark = tot;
+            if (first && cc + 1 < nch) {
+                issue_patch(cc + 1, (cc + 1) & 1);
+                tot += 4;
+                markp_nxt = tot;
             }
-            const float rb = d.row_bias ? d.row_bias[m] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e] * d.alpha + bia[e] + rb + rvv[e];
-                if (d.act == FRIDO_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (d.act == FRIDO_ACT_SILU) x = silu_f(x);
-                else if (d.act == FRIDO_ACT_GELU) x = gelu_f(x);
-                v[e] = x + res[e];
-            }
-            if (full) {
-                if (d.out_f32) {
-                    const int64_t o = of_base + (int64_t)m * d.ldo + n;
-                    if (d.out_bf16) {
-                        const uint2 pk = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
-                                                    f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
-                        *reinterpret_cast<uint2*>(reinterpret_cast<frido_bf16*>(d.out_f32) + o) = pk;
-                    } else {
-                        *reinterpret_cast<float4*>(d.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-                if (d.out_op) store_op4(d.out_op + oo_base, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
+            for (int q = 0; q < DB - 2; ++q) mark[q] = mark[q + 1];
+            mark[DB - 2] = newmark;
+        }
+        // ---- compute: tap shift = constant slot offset ----
+        const int dy = tc / 3 - 1, dx = tc - (tc / 3) * 3 - 1;
+        const int shift = dy * PW + dx;
+        const unsigned pbase = lds0 + (cc & 1) * P::PBUF + (kg << 4);
+        bf16x8 fa[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int sl = sbase[i] + shift;
+            fa[i] = lds_read128((pbase + (sl << 6)) ^ ((sl & 4) << 3));
+        }
+        const unsigned sbb = b_frag + stage * P::BSTAGE;
+        bf16x8 fb[2];
+        fb[0] = lds_read128(sbb);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (j + 1 < TN) {
+                fb[(j + 1) & 1] = lds_read128(sbb + (j + 1) * 16 * 64);
+                asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
             } else {
-                for (int e = 0; e < nv; ++e) {
-                    if (d.out_f32) store_act1(d.out_f32, of_base + (int64_t)m * d.ldo + n + e, d.out_bf16, v[e]);
-                    if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n + e, v[e]);
-                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j & 1], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- advance ----
+        stage = stage + 1 == DB ? 0 : stage + 1;
+        first = false;
+        if (cc < nc1 && tc < 8) ++tc;
+        else {
+            ++cc;
+            tc = cc < nc1 ? 0 : 4;
+            first = true;
+            markp_cur = markp_nxt;
         }
     }
+    tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
@@ -460,6 +739,30 @@ int launch(const FridoGemm& d, hipStream_t s) {
     return frido_check_launch("igemm");
 }
 
+// eligibility of the patch-staged 3x3 kernel (tile id 9)
+bool patch_ok(const FridoGemm& d) {
+    if (!d.conv || d.nsplit != 1 || d.batch != 1 || d.splitk > 1) return false;
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.up_shift || d.dn_shift) return false;
+    if (d.Ho != d.Hs || d.Wo != d.Ws || d.Hl != d.Hs || d.Wl != d.Ws) return false;
+    const int W = d.Ws, HW = d.Hs * d.Ws;
+    if (W < 8 || W > 64 || (W & (W - 1))) return false;
+    if (d.M % 256 || !((HW % 256) == 0 || (256 % HW) == 0)) return false;
+    const int RW = HW < 256 ? HW : 256, R = RW / W;
+    if ((256 / RW) * (R + 2) * (W + 2) > 512) return false;
+    if ((d.Cin & 31) || (d.K2 & 31) || d.K != 9 * d.Cin || (d.K2 && !d.A2)) return false;
+    return true;
+}
+
+int launch_patch(const FridoGemm& d, hipStream_t s) {
+    if (!patch_ok(d)) {
+        frido_set_error("igemm: tile 9 (patch-staged 3x3) does not apply to this convolution");
+        return FRIDO_EINVAL;
+    }
+    const int tiles = (d.M / 256) * ((d.N + 191) / 192);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<192>), dim3(tiles), dim3(512), PGeo<192>::SMEM, s, d);
+    return frido_check_launch("conv3x3_patch");
+}
+
 template <int NS, bool CONV>
 int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
     switch (tile) {
@@ -469,6 +772,9 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         case 5: return launch<64, 192, NS, CONV, 32>(d, s);
         case 6: return launch<64, 128, NS, CONV, 32>(d, s);
         default: break;
+    }
+    if constexpr (NS == 1 && CONV) {
+        if (tile == 9) return launch_patch(d, s);
     }
     if constexpr (NS == 1) {      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
         if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);
@@ -512,6 +818,11 @@ int frido_igemm_init() {
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
           set_attr<256, 256, 1, false, 32>();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PGeo<192>::SMEM) != hipSuccess) {
+        frido_set_error("igemm: cannot set dynamic LDS size of the patch kernel");
+        rc |= 1;
+    }
     return rc ? FRIDO_EHIP : FRIDO_OK;
 }
 

@@ -181,6 +181,53 @@ def test_conv(nsplit, case):
     assert _relerr(got, ref) < _tol(nsplit)
 
 
+PATCH_CASES = [   # B, H, W, Cin, Cout, Cskip (0 = no fused 1x1 skip operand)
+    (4, 64, 64, 64, 192, 0),     # one group = 4 image rows
+    (2, 32, 32, 96, 384, 0),     # 8 rows per tile, two N tiles
+    (1, 16, 16, 32, 100, 0),     # a whole image per tile, ragged N
+    (16, 8, 8, 64, 192, 0),      # four 8x8 images per tile
+    (2, 32, 64, 32, 64, 0),      # non-square plane
+    (4, 8, 16, 64, 192, 0),      # two 8x16 images per tile
+    (4, 32, 32, 128, 192, 64),   # fused 1x1 skip operand riding along as extra k-chunks
+    (16, 8, 8, 192, 960, 128),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv3x3_patch_staged_kernel(case):
+    """Tile id 9: the patch-staged 3x3 kernel (input patch DMA'd to LDS once per channel chunk, nine taps = LDS row
+    shifts) against F.conv2d, including the zero halo at image borders and between images that share a tile."""
+    B, H, W, Cin, Cout, Cs = case
+    x = _t("px", B, Cin, H, W)
+    w = _t("pw", Cout, Cin, 3, 3) / np.sqrt(Cin * 9)
+    bias = _t("pb", Cout)
+    ref = F.conv2d(x, w, bias, padding=1)
+    weights = {"c.weight": w.cuda(), "c.bias": bias.cuda()}
+    if Cs:
+        xs, wsk, bs = _t("psx", B, Cs, H, W), _t("psw", Cout, Cs, 1, 1) / np.sqrt(Cs), _t("psb", Cout)
+        ref = ref + F.conv2d(xs, wsk, bs)
+        weights.update({"s.weight": wsk.cuda(), "s.bias": bs.cuda()})
+    b = _builder(1, weights)
+    xd = x.cuda()
+    a = b.pack(xd.data_ptr(), B, H * W, Cin, 0, Cin, nchw=True)
+    if Cs:
+        xsd = xs.cuda()
+        raw = b.pack(xsd.data_ptr(), B, H * W, Cs, 0, Cs, nchw=True)
+        out = b.conv_plus_skip(a, raw, B, H, W, "c", "s")
+    else:
+        out = b.conv(a, B, H, W, "c")
+    b.prog.ops[-1][1].tile = 9
+    b.prog.ops[-1][1].splitk = 1
+    _run(b)
+    got = out.to_f32().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert _relerr(got, ref) < 2e-2
+    # same op on the ring kernel: the two must agree to accumulation-order noise
+    b.prog.ops[-1][1].tile = 2
+    _run(b)
+    got2 = out.to_f32().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert _relerr(got, got2) < 1e-2
+
+
 @pytest.mark.parametrize("C1,C2,HW", [(64, 0, 256), (96, 32, 64), (192, 0, 1024), (960, 576, 64), (32, 0, 16)])
 @pytest.mark.parametrize("spade", [False, True])
 def test_groupnorm_apply(C1, C2, HW, spade):

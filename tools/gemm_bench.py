@@ -14,7 +14,7 @@ from frido_amd.engine import require_gpu  # noqa: E402
 
 NAMES = {1: "128x128", 2: "128x192", 3: "64x64", 4: "128x64", 5: "64x192", 6: "64x128"}
 NAMES.update({k + 10: v + "k64" for k, v in list(NAMES.items())})
-NAMES.update({7: "256x128", 8: "256x256"})
+NAMES.update({7: "256x128", 8: "256x256", 9: "patch256x192"})
 
 
 def main():
@@ -50,6 +50,8 @@ def main():
     noepi = os.environ.get("NOEPI") == "1"
     if noepi:
         st.act = 99
+    if os.environ.get("NOEPI", "")[:1] in "23456789" and os.environ.get("NOEPI"):
+        st.act = 100 - int(os.environ["NOEPI"])
     for tile in tiles:
         st.tile = tile
         arr = _lib.pack_ops([(kind, st)] * reps)
