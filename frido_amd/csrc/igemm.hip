@@ -340,33 +340,38 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     const int kt0 = kz * per;
     const int nk = max(0, min(nk_all, kt0 + per) - kt0);
     const int cin = d.Cin, kw = d.kw, ws = d.Ws;
-    int kc = 0, ky = 0, kx = 0, tap = 0;   // conv k-walk (uniform): channel offset inside the tap, tap coordinates
-    int64_t tap_off = 0;                   // ((ky * Ws + kx) * Cin + kc): offset of the current k-tile from tap (0,0)
-    if (CONV && kt0) {
-        const int cpt = cin / BK;
-        tap = kt0 / cpt;
-        kc = (kt0 - tap * cpt) * BK;
-        ky = tap / kw;
-        kx = tap - ky * kw;
-        tap_off = ((int64_t)ky * ws + kx) * cin + kc;
-    }
     // keep the zero page's address in SGPRs (otherwise hipcc re-loads it from the GOT inside the k-loop)
     unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
     asm volatile("" : "+s"(zero_addr));
-    const int64_t a_lo = d.a_lo, b_lo = d.b_lo;
+    const int64_t b_lo = d.b_lo;
 
-    auto issue = [&](int kt, int buf) {
-        unsigned char* sb = smem + buf * STAGE + wave * 1024;
+    // ---- incremental source pointers.  Inside one SEGMENT of the k-walk (the channel chunks of one conv tap, the whole K of
+    //      a dense operand, the appended A2 range) every piece just advances by BK elements per k-tile; the per-piece
+    //      base, the tap's validity bit and the zero-page substitution are evaluated once per segment (`retap`).  The
+    //      previous form re-derived all of it per k-tile: ~100 scalar + vector instructions next to 24 MFMAs.
+    const frido_bf16* aptr[JA];
+    int astep[JA];                      // BK, or 0 for a piece parked on the zero page
+    const frido_bf16* bptr[JB];
 #pragma unroll
-        for (int j = 0; j < JA; ++j) {
-            const frido_bf16* src;
-            if (kt >= nk1) {                 // appended dense operand (fused 1x1 skip conv)
-                const int64_t off = a2_off[j] + (int64_t)(kt - nk1) * BK;
+    for (int j = 0; j < JB; ++j) bptr[j] = Bb + b_off[j] + (int64_t)kt0 * BK;
+    int ktn = kt0;                      // next k-tile to issue
+    int seg_left = 0;                   // k-tiles left in the current segment
+    int64_t alo_cur = d.a_lo;           // hi -> lo plane distance of the operand the segment reads
+    auto retap = [&]() {
+        if (ktn >= nk1) {               // appended dense operand (fused 1x1 skip conv): runs to the end of K
 #pragma unroll
-                for (int p = 0; p < NS; ++p)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(A2b + (p ? d.a2_lo : 0) + off),
-                                                     (lptr_t)(sb + p * PLANE + j * (NW * 1024)), 16, 0, 0);
-            } else if (CONV) {
+            for (int j = 0; j < JA; ++j) {
+                aptr[j] = A2b + a2_off[j] + (int64_t)(ktn - nk1) * BK;
+                astep[j] = BK;
+            }
+            alo_cur = d.a2_lo;
+            seg_left = 1 << 30;
+        } else if (CONV) {
+            const int cpt = cin / BK;
+            const int tap = ktn / cpt, kc = (ktn - tap * cpt) * BK;
+            const int ky = tap / kw, kx = tap - ky * kw;
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
                 const bool ok = (a_mask[j] >> tap) & 1u;
                 int64_t off;
                 if (resample) {   // Upsample / SPADE-resize convs: source pixel = ((iy >> up) << dn, (ix >> up) << dn)
@@ -374,40 +379,44 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                     const int sy = (iy >> d.up_shift) << d.dn_shift, sx = (ix >> d.up_shift) << d.dn_shift;
                     off = ((int64_t)(a_b[j] * d.Hs + sy) * d.Ws + sx) * d.Cin + kc + lq * 8;
                 } else {
-                    off = a_off[j] + tap_off;
+                    off = a_off[j] + ((int64_t)ky * ws + kx) * cin + kc;
                 }
-#pragma unroll
-                for (int p = 0; p < NS; ++p) {
-                    src = ok ? Ab + (p ? a_lo : 0) + off : reinterpret_cast<const frido_bf16*>(zero_addr);
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * (NW * 1024)), 16, 0, 0);
-                }
-            } else {
-                const int64_t off = a_off[j] + (int64_t)kt * BK;
-#pragma unroll
-                for (int p = 0; p < NS; ++p) {
-                    src = Ab + (p ? a_lo : 0) + off;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + p * PLANE + j * (NW * 1024)), 16, 0, 0);
-                }
+                aptr[j] = ok ? Ab + off : reinterpret_cast<const frido_bf16*>(zero_addr);
+                astep[j] = ok ? BK : 0;
             }
+            const int in_tap = cpt - kc / BK, to_end = nk1 - ktn;
+            seg_left = in_tap < to_end ? in_tap : to_end;
+        } else {
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                aptr[j] = Ab + a_off[j] + (int64_t)ktn * BK;
+                astep[j] = BK;
+            }
+            seg_left = nk1 - ktn;
+        }
+    };
+
+    auto issue = [&](int buf) {
+        if (seg_left == 0) retap();
+        unsigned char* sb = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(sb + j * (NW * 1024)), 16, 0, 0);
+            if (NS == 2) {
+                const frido_bf16* lo = astep[j] ? aptr[j] + alo_cur : aptr[j];
+                __builtin_amdgcn_global_load_lds((gptr_t)lo, (lptr_t)(sb + PLANE + j * (NW * 1024)), 16, 0, 0);
+            }
+            aptr[j] += astep[j];
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            const int64_t off = b_off[j] + (int64_t)kt * BK;
-#pragma unroll
-            for (int p = 0; p < NS; ++p)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (p ? b_lo : 0) + off),
-                                                 (lptr_t)(sb + p * PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+            if (NS == 2)
+                __builtin_amdgcn_global_load_lds((gptr_t)(bptr[j] + b_lo), (lptr_t)(sb + PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+            bptr[j] += BK;
         }
-        if (CONV && kt < nk1) {   // advance the (tap, channel) walk
-            kc += BK;
-            tap_off += BK;
-            if (kc == cin) {
-                kc = 0;
-                ++tap;
-                if (++kx == kw) { kx = 0; ++ky; }
-                tap_off = ((int64_t)ky * ws + kx) * cin;
-            }
-        }
+        ++ktn;
+        --seg_left;
     };
 
     f32x4 acc[TM][TN];
@@ -427,7 +436,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     // ---- prologue: fill D-1 stages ----
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
-        if (s < nk) issue(kt0 + s, s);
+        if (s < nk) issue(s);
 
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -438,7 +447,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         if (kt + D - 1 < nk) {
             int nb_ = buf + D - 1;
             nb_ = nb_ >= D ? nb_ - D : nb_;
-            issue(kt0 + kt + D - 1, nb_);
+            issue(nb_);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {

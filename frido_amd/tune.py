@@ -92,7 +92,7 @@ def best_tile(st, device, stream):
     best, best_t = (0, 1), float("inf")
     nk = (st.K + st.K2) // 32
     small = st.batch == 1 and st.M * st.N <= (1 << 23) and not st.geglu       # split-K only pays for small outputs with a long K
-    splits = [1] + [k for k in (2, 4, 8) if small and nk >= 8 * k]
+    splits = [1] + [k for k in (2, 3, 4, 6, 8, 12, 16) if small and nk >= 8 * k]
     for sk in splits:
         t.splitk = sk
         t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None
@@ -102,8 +102,6 @@ def best_tile(st, device, stream):
         big = st.nsplit == 1 and sk == 1 and st.M >= 512 and st.N >= 96
         for tile in TILES + (TILES64 if k64 else ()) + (TILES8W if big else ()):
             if tile % 10 in (1, 2, 4) and st.M < 64:
-                continue
-            if sk > 1 and tile % 10 in (1, 2):
                 continue
             t.tile = tile
             arr = _lib.pack_ops([(kind, t)] * (reps + 1))

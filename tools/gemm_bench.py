@@ -52,6 +52,10 @@ def main():
         st.act = 99
     if os.environ.get("NOEPI", "")[:1] in "23456789" and os.environ.get("NOEPI"):
         st.act = 100 - int(os.environ["NOEPI"])
+    sk = int(os.environ.get("SPLITK", "1"))
+    if sk > 1:
+        st.splitk = sk
+        st.ws = tune.workspace(dev, sk * st.M * st.N * 4)
     for tile in tiles:
         st.tile = tile
         arr = _lib.pack_ops([(kind, st)] * reps)
