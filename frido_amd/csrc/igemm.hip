@@ -577,8 +577,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     const frido_bf16* __restrict__ A2b = d.A2;
     const frido_bf16* __restrict__ Bb = d.B;
     const int cin = d.Cin;
-    const int nc1 = cin >> 5, nc2 = d.K2 >> 5, nch = nc1 + nc2;
-    const int S = 9 * nc1 + nc2;
+    const int nc1 = cin >> 5, nc2 = d.K2 >> 5, nch_all = nc1 + nc2;
+    // split-K: gridDim.z slices of the 32-channel chunk sequence (a conv chunk = 9 k-tiles, an A2 chunk = 1)
+    const int kz = blockIdx.z;
+    const int c_begin = (int)((long)nch_all * kz / (int)gridDim.z), nch = (int)((long)nch_all * (kz + 1) / (int)gridDim.z);
+    const int ncv = (nch < nc1 ? nch : nc1) - (c_begin < nc1 ? c_begin : nc1);        // conv chunks in [c_begin, nch)
+    const int S = 9 * ncv + (nch - c_begin - ncv);
     unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
     asm volatile("" : "+s"(zero_addr));
 
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
         }
     };
     // issue-side k-walk (uniform): chunk / tap of the next weight stage to fetch
-    int ic = 0, it = nc1 > 0 ? 0 : 4;
+    int ic = c_begin, it = c_begin < nc1 ? 0 : 4;
     auto issue_b = [&](int stage) {
         const int64_t koff = ic < nc1 ? (int64_t)it * cin + ic * 32 : (int64_t)d.K + (ic - nc1) * 32;
         unsigned char* dst = smem + P::B0 + stage * P::BSTAGE + wave * 1024;
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
 
     // ---- prologue ----
     int tot = 0;                      // DMA pieces this wave has issued
-    issue_patch(0, 0);
+    issue_patch(c_begin, c_begin & 1);
     tot += 4;
     int markp_cur = tot, markp_nxt = tot;      // issue count right after the current / next chunk's patch
     int mark[DB - 1];                          // ... right after the weight stages of steps s .. s+DB-2
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
         mark[s] = tot;
     }
 
-    int cc = 0, tc = nc1 > 0 ? 0 : 4;          // compute-side k-walk
+    int cc = c_begin, tc = c_begin < nc1 ? 0 : 4;   // compute-side k-walk
     int stage = 0;
     bool first = true;                         // first step of chunk cc
     for (int s = 0; s < S; ++s) {
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
             markp_cur = markp_nxt;
         }
     }
-    tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, 0);
+    tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
@@ -750,7 +754,8 @@ int launch(const FridoGemm& d, hipStream_t s) {
 
 // eligibility of the patch-staged 3x3 kernel (tile id 9)
 bool patch_ok(const FridoGemm& d) {
-    if (!d.conv || d.nsplit != 1 || d.batch != 1 || d.splitk > 1) return false;
+    if (!d.conv || d.nsplit != 1 || d.batch != 1) return false;
+    if (d.splitk > 1 && (!d.ws || d.splitk > ((d.Cin + d.K2) >> 5))) return false;
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.up_shift || d.dn_shift) return false;
     if (d.Ho != d.Hs || d.Wo != d.Ws || d.Hl != d.Hs || d.Wl != d.Ws) return false;
     const int W = d.Ws, HW = d.Hs * d.Ws;
@@ -768,7 +773,13 @@ int launch_patch(const FridoGemm& d, hipStream_t s) {
         return FRIDO_EINVAL;
     }
     const int tiles = (d.M / 256) * ((d.N + 191) / 192);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<192>), dim3(tiles), dim3(512), PGeo<192>::SMEM, s, d);
+    const int sk = d.splitk > 1 ? d.splitk : 1;
+    hipLaunchKernelGGL((conv3x3_patch_kernel<192>), dim3(tiles, 1, sk), dim3(512), PGeo<192>::SMEM, s, d);
+    if (sk > 1) {
+        const int64_t total = (int64_t)d.M * d.N;
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
+    }
     return frido_check_launch("conv3x3_patch");
 }
 

@@ -226,6 +226,19 @@ def test_conv3x3_patch_staged_kernel(case):
     _run(b)
     got2 = out.to_f32().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
     assert _relerr(got, got2) < 1e-2
+    # split-K over the 32-channel chunk sequence (partials in a workspace, reduced by splitk_reduce_kernel)
+    from frido_amd import tune
+    st = b.prog.ops[-1][1]
+    nchunks = (st.Cin + st.K2) // 32
+    for sk in (2, 3):
+        if sk > nchunks:
+            continue
+        st.tile, st.splitk = 9, sk
+        st.ws = tune.workspace(_dev(), sk * st.M * st.N * 4)
+        out.view().zero_()
+        _run(b)
+        got3 = out.to_f32().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+        assert _relerr(got3, ref) < 2e-2, sk
 
 
 @pytest.mark.parametrize("C1,C2,HW", [(64, 0, 256), (96, 32, 64), (192, 0, 1024), (960, 576, 64), (32, 0, 16)])
