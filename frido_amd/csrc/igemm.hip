@@ -707,6 +707,87 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
 }
 
+// split-K reduction + epilogue, 8 columns per thread (16-byte accesses; N % 8 == 0 and 8-element aligned strides)
+__global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) {
+    const int n8 = d.N >> 3;
+    const unsigned total = (unsigned)d.M * (unsigned)n8;
+    int vstep = 0;
+    if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
+    const int64_t plane = (int64_t)d.M * d.N;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int m = (int)(i / (unsigned)n8), n = (int)(i - (unsigned)m * (unsigned)n8) * 8;
+        const float* w = d.ws + (int64_t)m * d.N + n;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int z = 0; z < d.splitk; ++z) {
+            const float4 a = *reinterpret_cast<const float4*>(w + z * plane), b = *reinterpret_cast<const float4*>(w + z * plane + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        float add[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) add[e] = d.row_bias ? d.row_bias[m] : 0.f;
+        if (d.bias) {
+            const float4 a = *reinterpret_cast<const float4*>(d.bias + n), b = *reinterpret_cast<const float4*>(d.bias + n + 4);
+            add[0] += a.x; add[1] += a.y; add[2] += a.z; add[3] += a.w; add[4] += b.x; add[5] += b.y; add[6] += b.z; add[7] += b.w;
+        }
+        if (d.rowvec) {
+            const float* rp = d.rowvec + (int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n;
+            const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
+            add[0] += a.x; add[1] += a.y; add[2] += a.z; add[3] += a.w; add[4] += b.x; add[5] += b.y; add[6] += b.z; add[7] += b.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + add[e];
+        if (d.act == FRIDO_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (d.act == FRIDO_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else if (d.act == FRIDO_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (d.residual) {
+            const int64_t ro = (int64_t)m * d.ldr + n;
+            if (d.res_bf16) {
+                const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const frido_bf16*>(d.residual) + ro);
+                v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+            } else {
+                const float* rp = reinterpret_cast<const float*>(d.residual) + ro;
+                const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+        }
+        if (d.out_f32) {
+            const int64_t o = (int64_t)m * d.ldo + n;
+            if (d.out_bf16) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<frido_bf16*>(d.out_f32) + o) =
+                    make_uint4(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16),
+                               f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16), f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16));
+            } else {
+                *reinterpret_cast<float4*>(d.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(d.out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+        if (d.out_op) {
+            uint32_t h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+            frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + n;
+            *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            if (d.nsplit == 2)
+                *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        }
+    }
+}
+
+// launch the split-K reduction that matches the descriptor's alignment
+void launch_splitk_reduce(const FridoGemm& d, hipStream_t s);
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
     const int64_t total = (int64_t)d.M * d.N;
     int vstep = 0;
@@ -727,6 +808,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
     }
 }
 
+void launch_splitk_reduce(const FridoGemm& d, hipStream_t s) {
+    const bool vec8 = ((d.N | d.ldo | d.ldr | d.ldoo | d.ldv | d.oo_lo) & 7) == 0;
+    const int64_t total = vec8 ? (int64_t)d.M * (d.N >> 3) : (int64_t)d.M * d.N;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (vec8) hipLaunchKernelGGL(splitk_reduce8_kernel, dim3(blocks), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
+}
+
 template <int BM, int BN, int NS, bool CONV, int BK>
 int set_attr() {
     constexpr int smem = Geo<BM, BN, NS, BK>::SMEM;
@@ -745,9 +834,7 @@ int launch(const FridoGemm& d, hipStream_t s) {
     const int sk = d.splitk > 1 ? d.splitk : 1;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK>::NT), smem, s, d);
     if (sk > 1) {
-        const int64_t total = (int64_t)d.M * d.N;
-        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
+        launch_splitk_reduce(d, s);
     }
     return frido_check_launch("igemm");
 }
@@ -776,9 +863,7 @@ int launch_patch(const FridoGemm& d, hipStream_t s) {
     const int sk = d.splitk > 1 ? d.splitk : 1;
     hipLaunchKernelGGL((conv3x3_patch_kernel<192>), dim3(tiles, 1, sk), dim3(512), PGeo<192>::SMEM, s, d);
     if (sk > 1) {
-        const int64_t total = (int64_t)d.M * d.N;
-        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
+        launch_splitk_reduce(d, s);
     }
     return frido_check_launch("conv3x3_patch");
 }
