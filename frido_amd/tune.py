@@ -1,7 +1,11 @@
 """Plan-time tile selection for the implicit-GEMM kernel: each distinct GEMM signature is timed once per
 process on scratch buffers with every tile shape (HIP events on the launch stream) and the fastest wins.
-Disable with FRIDO_TUNE=0 (the C library's static heuristic is used instead)."""
+Disable with FRIDO_TUNE=0 (the C library's static heuristic is used instead).  FRIDO_TUNE_CACHE=<file> persists the
+choices across processes (JSON; keyed by the GEMM signature and the size of libfrido_hip.so, so a rebuilt library starts
+over) -- used to profile under rocprofv3 --pmc, where re-timing thousands of candidates would take hours."""
+import atexit
 import ctypes as C
+import json
 import os
 
 import torch
@@ -14,6 +18,40 @@ TILES8W = (7, 8)                    # 8-wave 256-row tiles (bf16 mode)
 _cache = {}
 _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
+CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
+_dirty = False
+
+
+def _lib_tag():
+    try:
+        return str(os.path.getsize(_lib.LIB_PATH))
+    except OSError:
+        return "?"
+
+
+def _load_cache():
+    if not CACHE_FILE or not os.path.exists(CACHE_FILE):
+        return
+    try:
+        blob = json.load(open(CACHE_FILE))
+    except (OSError, ValueError):
+        return
+    if blob.get("lib") != _lib_tag():
+        return
+    for k, v in blob.get("entries", []):
+        _cache[tuple(k)] = tuple(v)
+
+
+def _save_cache():
+    if CACHE_FILE and _dirty:
+        tmp = CACHE_FILE + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump({"lib": _lib_tag(), "entries": [[list(k), list(v)] for k, v in _cache.items()]}, f)
+        os.replace(tmp, CACHE_FILE)
+
+
+_load_cache()
+atexit.register(_save_cache)
 
 _SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
                "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
@@ -113,4 +151,6 @@ def best_tile(st, device, stream):
             if dt < best_t:
                 best, best_t = (tile, sk), dt
     _cache[sig] = best
+    global _dirty
+    _dirty = True
     return best
