@@ -2,12 +2,17 @@
 descriptors, owning the packed-weight cache and the activation pool.  The U-Net / VQGAN plans
 (unet_plan.py, vqgan_plan.py) are written against this API; the kernel unit tests drive it directly.
 """
+import ctypes as C_
+import os
+
 import torch
 
 from . import _lib
 from .engine import (Operand, POperand, F32, Alias, Pool, Prog, pack_matrix, pack_conv_weight, rup)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
+GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
 
 
 class Builder:
@@ -271,21 +276,28 @@ class Builder:
                   out_f32=False):
         """GroupNorm(32) [+SPADE] [+SiLU] of the (virtually concatenated) NHWC f32 input -> operand."""
         C = x1.C + (x2.C if x2 is not None else 0)
-        part, S = self.gn_stats(x1, x2, B, HW)
         a = self.op(B * HW, C)
         xb = getattr(x1, "bf16", False)
         alias_raw = want_raw and xb and x2 is None          # a bf16 activation already IS its own operand
         raw = None if (not want_raw or alias_raw) else self.op(B * HW, C)
         of = self.f32_strict(B * HW, C) if out_f32 else None
-        self.prog.emit("FRIDO_OP_GN_APPLY", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
-                       C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=S, partials=part.data_ptr(),
-                       eps=eps, weight=self.bias(wname + ".weight"), bias=self.bias(wname + ".bias"),
-                       gamma=gamma.ptr if gamma is not None else None, beta=beta.ptr if beta is not None else None,
-                       act=act, nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo,
-                       raw_op=raw.ptr if raw is not None else None, raw_lo=raw.lo if raw is not None else 0,
-                       out_f32=of.ptr if of is not None else None, x_bf16=int(xb),
-                       gb_bf16=int(getattr(gamma, "bf16", False)) if gamma is not None else 0)
-        self.pool.release(part)
+        kw = dict(x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None, C2=x2.C if x2 is not None else 0, B=B, HW=HW,
+                  groups=32, eps=eps, weight=self.bias(wname + ".weight"), bias=self.bias(wname + ".bias"),
+                  gamma=gamma.ptr if gamma is not None else None, beta=beta.ptr if beta is not None else None,
+                  act=act, nsplit=self.nsplit, out_op=a.ptr, out_lo=a.lo,
+                  raw_op=raw.ptr if raw is not None else None, raw_lo=raw.lo if raw is not None else 0,
+                  out_f32=of.ptr if of is not None else None, x_bf16=int(xb),
+                  gb_bf16=int(getattr(gamma, "bf16", False)) if gamma is not None else 0)
+        # one launch (statistics + apply from registers) wherever a (sample, group-chunk) slice fits a workgroup
+        _, probe = _lib.make_op("FRIDO_OP_GN_FUSED", **kw)
+        if GN_FUSED and HW <= GN_FUSED_MAX_HW and _lib.lib().frido_gn_fused_chunk(C_.byref(probe), None) > 0:
+            self.prog.emit("FRIDO_OP_GN_FUSED", **kw)
+            part = None
+        else:
+            part, S = self.gn_stats(x1, x2, B, HW)
+            self.prog.emit("FRIDO_OP_GN_APPLY", nsplit_px=S, partials=part.data_ptr(), **kw)
+        if part is not None:
+            self.pool.release(part)
         if alias_raw:
             raw = Alias(x1)
         if out_f32:

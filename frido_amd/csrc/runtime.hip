@@ -54,6 +54,7 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_EMBED: return frido_embed(&op.u.embed, s);
         case FRIDO_OP_TO_U8: return frido_to_u8(&op.u.to_u8, s);
         case FRIDO_OP_ATTN_SMALL: return frido_attn_small(&op.u.attn_small, s);
+        case FRIDO_OP_GN_FUSED: return frido_gn_fused(&op.u.gn_apply, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -230,6 +231,7 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_EMBED: return sizeof(FridoEmbed);
         case FRIDO_OP_TO_U8: return sizeof(FridoToU8);
         case FRIDO_OP_ATTN_SMALL: return sizeof(FridoAttnSmall);
+        case FRIDO_OP_GN_FUSED: return sizeof(FridoGnApply);
         default: return -1;
     }
 }

@@ -255,7 +255,7 @@ typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -291,6 +291,11 @@ int frido_place(const FridoPlace* d, frido_stream_t s);
 int frido_embed(const FridoEmbed* d, frido_stream_t s);
 int frido_to_u8(const FridoToU8* d, frido_stream_t s);
 int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s);
+/* One-launch GroupNorm (statistics + apply) on a FridoGnApply descriptor whose `partials` is unused; bf16 stream only.
+ * frido_gn_fused_chunk returns the channel-chunk width it would use (and the workgroup size), or 0 if the descriptor does
+ * not qualify -- then gn_stats + gn_apply is the path. */
+int frido_gn_fused(const FridoGnApply* d, frido_stream_t s);
+int frido_gn_fused_chunk(const FridoGnApply* d, int* nthreads);
 
 /* ---- native executor: run / capture a whole program ---- */
 int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s);

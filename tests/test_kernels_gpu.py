@@ -276,6 +276,45 @@ def test_groupnorm_apply(C1, C2, HW, spade):
     assert _relerr(raw.to_f32().cpu(), xc.reshape(B * HW, C)) < 2e-5
 
 
+@pytest.mark.parametrize("C1,C2,HW", [(960, 0, 64), (576, 0, 256), (384, 0, 1024), (192, 0, 4096), (960, 960, 64), (960, 576, 256),
+                                      (192, 192, 4096), (64, 0, 256), (96, 32, 64), (576, 0, 4096)])
+@pytest.mark.parametrize("spade", [False, True])
+def test_groupnorm_bf16_stream_one_launch(C1, C2, HW, spade):
+    """bf16 stream: the one-launch GroupNorm (gn_fused_kernel) where a (sample, group-chunk) slice fits a workgroup, the
+    gn_stats + gn_apply pair elsewhere -- both against F.group_norm on the bf16-rounded input."""
+    from frido_amd import _lib
+    from frido_amd.builder import ACT_SILU
+    B, C = 3, C1 + C2
+    x1 = (_t("h1", B, HW, C1) * 2 + 0.5).to(torch.bfloat16).float()
+    x2 = _t("h2", B, HW, C2).to(torch.bfloat16).float() if C2 else None
+    w, bi = 1 + 0.1 * _t("hw", C), 0.1 * _t("hb", C)
+    gam, bet = ((_t("hg", B, HW, C) * 0.5).to(torch.bfloat16).float(), _t("hbt", B, HW, C).to(torch.bfloat16).float()) if spade else (None, None)
+    b = _builder(1, {"n.weight": w.cuda(), "n.bias": bi.cuda()})
+    f1 = b.f32(B * HW, C1)
+    f1.view().copy_(x1.view(B * HW, C1).cuda())
+    f2 = None
+    if C2:
+        f2 = b.f32(B * HW, C2)
+        f2.view().copy_(x2.view(B * HW, C2).cuda())
+    g = be = None
+    if spade:
+        g, be = b.f32(B * HW, C), b.f32(B * HW, C)
+        g.view().copy_(gam.view(-1, C).cuda())
+        be.view().copy_(bet.view(-1, C).cuda())
+    a, raw = b.groupnorm(f1, f2, B, HW, "n", 1e-5, gamma=g, beta=be, act=ACT_SILU, want_raw=True)
+    kinds = [k for k, _ in b.prog.ops]
+    fused = _lib.OP_KINDS["FRIDO_OP_GN_FUSED"] in kinds
+    assert fused == (HW <= 256)           # larger planes keep the two coalesced kernels (builder.GN_FUSED_MAX_HW)
+    _run(b)
+    xc = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    ref = F.group_norm(xc.permute(0, 2, 1).reshape(B, C, HW, 1), 32, w, bi, 1e-5)
+    if spade:
+        ref = ref * (1 + gam.permute(0, 2, 1).reshape(B, C, HW, 1)) + bet.permute(0, 2, 1).reshape(B, C, HW, 1)
+    ref = F.silu(ref).reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
+    assert _relerr(a.to_f32().cpu(), ref) < 1e-2              # bf16 output rounding
+    assert torch.equal(raw.to_f32().cpu(), xc.reshape(B * HW, C))
+
+
 def test_bf16_residual_stream_inputs():
     """bf16 mode keeps the residual stream in bf16: GroupNorm / LayerNorm / residual epilogue read it directly."""
     from frido_amd.builder import ACT_SILU
