@@ -129,22 +129,37 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = acc[ii][j][e];
             }
-        if (d.geglu) {       // 16-column blocks alternate [a | gate] (attention.py:42-44): every lane makes 4 outputs
-            constexpr int LPRG = WC / 8, RPPG = 64 / LPRG;
-            const int gr = lane / LPRG, gc = (lane - gr * LPRG) * 4;          // row, first OUTPUT column of this lane
+        if (d.geglu) {       // 16-column blocks alternate [a | gate] (attention.py:42-44): every lane makes 8 outputs
+            constexpr int LPRG = WC / 16, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16;
+            const int gr = lane / LPRG, gc = (lane - gr * LPRG) * 8;          // row, first OUTPUT column of this lane
             const int ac = (gc >> 4) * 32 + (gc & 15);                        // column of `a` inside the wave's slab
+            const int n = nbase + ac;
+            float ba[8], bg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ba[e] = bg[e] = 0.f;
+            if (d.bias && lane < RPPG * LPRG && n + 16 < d.N) {
+                const float4 t0 = *reinterpret_cast<const float4*>(d.bias + n), t1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+                const float4 u0 = *reinterpret_cast<const float4*>(d.bias + n + 16), u1 = *reinterpret_cast<const float4*>(d.bias + n + 20);
+                ba[0] = t0.x; ba[1] = t0.y; ba[2] = t0.z; ba[3] = t0.w; ba[4] = t1.x; ba[5] = t1.y; ba[6] = t1.z; ba[7] = t1.w;
+                bg[0] = u0.x; bg[1] = u0.y; bg[2] = u0.z; bg[3] = u0.w; bg[4] = u1.x; bg[5] = u1.y; bg[6] = u1.z; bg[7] = u1.w;
+            }
+#pragma unroll 1
             for (int ps = 0; ps < 16; ps += RPPG) {
                 const int r = ps + gr;
                 const int m = m0 + wm * WR + i * 16 + r;
-                const int n = nbase + ac;
                 if (lane >= RPPG * LPRG || r >= 16 || m >= d.M || n + 16 >= d.N) continue;
-                const float4 a4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac);
-                const float4 g4 = *reinterpret_cast<const float4*>(ep + r * EPS + ac + 16);
-                float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-                if (d.bias) { ba = *reinterpret_cast<const float4*>(d.bias + n); bg = *reinterpret_cast<const float4*>(d.bias + n + 16); }
-                const float o[4] = {(a4.x * d.alpha + ba.x) * gelu_f(g4.x * d.alpha + bg.x), (a4.y * d.alpha + ba.y) * gelu_f(g4.y * d.alpha + bg.y),
-                                    (a4.z * d.alpha + ba.z) * gelu_f(g4.z * d.alpha + bg.z), (a4.w * d.alpha + ba.w) * gelu_f(g4.w * d.alpha + bg.w)};
-                store_op4(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + (n >> 5) * 16 + (n & 15), o);
+                const float* sa = ep + r * EPS + ac;
+                const float4 a0 = *reinterpret_cast<const float4*>(sa), a1 = *reinterpret_cast<const float4*>(sa + 4);
+                const float4 g0 = *reinterpret_cast<const float4*>(sa + 16), g1 = *reinterpret_cast<const float4*>(sa + 20);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                uint32_t h[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split_bf16(fmaf(av[e], d.alpha, ba[e]) * gelu_f(fmaf(gv[e], d.alpha, bg[e])), h[e], l[e]);
+                frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + (n >> 5) * 16 + (n & 15);
+                *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                if (d.nsplit == 2)
+                    *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
             continue;
         }

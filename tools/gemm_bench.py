@@ -33,6 +33,15 @@ def main():
         xo = b.pack(x.data_ptr(), 1, B * H * W, Cin, 0, Cin)
         b.conv(xo, B, H, W, "c")
         flops = 2.0 * B * H * W * Cout * 9 * Cin
+    elif mode == "geglu":      # python tools/gemm_bench.py geglu M H K  (fused a * gelu(gate) projection, attention.py:37-44)
+        M, H, K = map(int, a[1:4])
+        rest = a[4:]
+        ns = int(rest[0]) if rest else 1
+        b = Builder(dev, ns, {"w.weight": torch.randn(2 * H, K, device=dev) * 0.05, "w.bias": torch.zeros(2 * H, device=dev)})
+        x = torch.randn(M, K, device=dev)
+        xo = b.pack(x.data_ptr(), 1, M, K, 0, K)
+        b.linear_geglu(xo, "w")
+        flops = 2.0 * M * 2 * H * K
     else:
         M, N, K = map(int, a[1:4])
         rest = a[4:]
