@@ -11,6 +11,7 @@ from . import _lib
 from .engine import (Operand, POperand, F32, Alias, Pool, Prog, pack_matrix, pack_conv_weight, rup)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample convs as four 2x2 phase convolutions
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
 
@@ -201,6 +202,51 @@ class Builder:
         res = self.f32(M, co)
         self.prog.gemm(M, co, kh * kw * cp, a, wop, ldb=kh * kw * cp + k2, conv=geom, bias=bsum.data_ptr(), out_f32=res.ptr, ldo=co,
                        out_bf16=res.bf16, A2=raw, lda2=raw.K, K2=k2)
+        return res
+
+    def up2_phase_weights(self, wname):
+        """nearest x2 upsample -> conv3x3 (pad 1) as four 2x2 PHASE convolutions on the source plane: output pixel
+        (2y+a, 2x+b) reads source rows {y-1, y} (a = 0) or {y, y+1} (a = 1) -- and likewise columns -- with the 3x3 taps that
+        land on the same source pixel summed (float64).  Returns the operand [4][Cout][4 Cin_pad] of the phases
+        (a, b) = (0,0), (0,1), (1,0), (1,1) (top / left padding of a phase: 1 - a, 1 - b)."""
+        key = ("up2", wname)
+        if key not in self._wcache:
+            w = self.w[wname + ".weight"].double()            # [Cout][Cin][3][3]
+            co, ci = w.shape[:2]
+            cp = rup(ci, 32)
+            rows = {0: [w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 1: [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]}     # [ty] -> [Cout][Cin][3(kx)]
+            mats = []
+            for a_ in (0, 1):
+                for b_ in (0, 1):
+                    wk = torch.zeros((co, 2, 2, cp), dtype=torch.float64, device=w.device)
+                    for ty in (0, 1):
+                        r = rows[a_][ty]                      # [Cout][Cin][3]
+                        cols = [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if b_ == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
+                        for tx in (0, 1):
+                            wk[:, ty, tx, :ci] = cols[tx]
+                    mats.append(wk.reshape(co, -1))
+            self._wcache[key] = (pack_matrix(torch.cat(mats, dim=0).float(), self.nsplit), cp)      # [4 Cout][4 Cin_pad]
+        return self._wcache[key]
+
+    def upsample_conv(self, a, B, Hs, Ws, wname):
+        """Upsample block: nearest x2 + conv3x3.  Four 2x2 phase convolutions when the plane allows it, else the 9-tap
+        conv with the up-sampling folded into its addressing."""
+        if UP2_PHASES and Hs & (Hs - 1) == 0 and Ws & (Ws - 1) == 0:
+            return self.conv_up2(a, B, Hs, Ws, wname)
+        return self.conv(a, B, Hs, Ws, wname, up=1)
+
+    def conv_up2(self, a, B, Hs, Ws, wname):
+        """Upsample (nearest x2) + conv3x3 of the NHWC operand `a` -> stream activation [B*2Hs*2Ws][Cout] (4/9 of the MACs of
+        the conv on the upsampled plane; pyunet.py:110-121, taming model.py:49-53)."""
+        wop, cp = self.up2_phase_weights(wname)
+        co = self.w[wname + ".weight"].shape[0]
+        assert a.K == cp and Hs & (Hs - 1) == 0 and Ws & (Ws - 1) == 0
+        res = self.f32(B * 4 * Hs * Ws, co)
+        geom = dict(Hs=Hs, Ws=Ws, Cin=cp, Hl=Hs, Wl=Ws, Ho=Hs, Wo=Ws, kh=2, kw=2, stride=1, pad=1, padx=1, up_shift=0, dn_shift=0,
+                    up2_phase=5)
+        # one launch: batch index = phase (weights co * 4 cp apart), every phase reads the same source and interleaves its rows
+        self.prog.gemm(B * Hs * Ws, co, 4 * cp, a, wop, batch=4, b_bs=co * 4 * cp, conv=geom, bias=self.bias(wname + ".bias"),
+                       out_f32=res.ptr, ldo=co, out_bf16=res.bf16)
         return res
 
     def conv(self, a, B, Hs, Ws, wname, *, stride=1, pad=1, up=0, dn=0, Ho=None, Wo=None, bias=True,

@@ -108,6 +108,16 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
     const int64_t rs_base = (int64_t)zo * d.res_bs;
     float* wsp = gridDim.z > 1 ? d.ws + (int64_t)kz * d.M * d.N : nullptr;
     constexpr int NP = (16 + RPP8 - 1) / RPP8;                         // passes per 16-row slab
+    // 2x2 phase convolution of an upsample: GEMM row (img, y, x) -> output row (img, 2y + a, 2x + b); Ho, Wo powers of two
+    const int up2 = d.up2_phase == 5 ? zo + 1 : d.up2_phase;
+    const int lw = 31 - __builtin_clz((unsigned)(d.Wo > 0 ? d.Wo : 1)), lhw = lw + 31 - __builtin_clz((unsigned)(d.Ho > 0 ? d.Ho : 1));
+    auto out_row = [&](int m) -> int64_t {
+        if (!up2) return m;
+        const int img = m >> lhw, rem = m & ((1 << lhw) - 1);
+        const int y = rem >> lw, x = rem & ((1 << lw) - 1);
+        const int a = (up2 - 1) >> 1, bq = (up2 - 1) & 1;
+        return ((int64_t)(img * 2 * d.Ho + 2 * y + a) * (2 * d.Wo)) + 2 * x + bq;
+    };
     // per-lane invariants: this lane's 8 columns are the same in every pass of every slab
     const int ncol = nbase + ec8;
     const bool fast = vec_ok && (d.N & 7) == 0;        // every lane's 8 columns are then all inside or all outside N
@@ -179,8 +189,9 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 else if (d.act == FRIDO_ACT_SILU) x = silu_f(x);
                 else if (d.act == FRIDO_ACT_GELU) x = gelu_f(x);
                 if (d.residual) x += load_act1(d.residual, rs_base + (int64_t)m * d.ldr + n, d.res_bf16);
-                if (d.out_f32) store_act1(d.out_f32, of_base + (int64_t)m * d.ldo + n, d.out_bf16, x);
-                if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, x);
+                const int64_t mo = out_row(m);
+                if (d.out_f32) store_act1(d.out_f32, of_base + mo * d.ldo + n, d.out_bf16, x);
+                if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, mo * d.ldoo + n, x);
             }
             continue;
         }
@@ -237,7 +248,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             }
             if (d.act == 98) { if (v[0] == 1.2345e-30f) d.out_f32[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; continue; }
             if (d.out_f32) {
-                const int64_t o = of_base + (int64_t)m * d.ldo + n;
+                const int64_t o = of_base + out_row(m) * d.ldo + n;
                 if (d.out_bf16) {
                     *reinterpret_cast<uint4*>(reinterpret_cast<frido_bf16*>(d.out_f32) + o) =
                         make_uint4(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16),
@@ -251,7 +262,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 uint32_t h[8], l[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
-                frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + n;
+                frido_bf16* op = d.out_op + oo_base + out_row(m) * d.ldoo + n;
                 *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 if (d.nsplit == 2)
                     *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
@@ -302,6 +313,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                             : (lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7);
     // conv: element offset of tap (0,0) of this row's receptive field + a bit mask of the taps that fall inside
     // the (logical) input; with resampling folded in (up/dn shifts) the per-tap offsets are tabulated instead
+    // all four phases of an upsample conv in one launch (up2_phase == 5): phase = batch index, padding follows the phase
+    const int pady = d.up2_phase == 5 ? 1 - (zo >> 1) : d.pad, padx = d.up2_phase == 5 ? 1 - (zo & 1) : d.padx;
     int64_t a_off[JA];
     unsigned a_mask[JA];
     const bool resample = CONV && (d.up_shift | d.dn_shift) != 0;
@@ -320,11 +333,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             unsigned mask = 0;
             for (int ty = 0; ty < d.kh; ++ty)
                 for (int tx = 0; tx < d.kw; ++tx) {
-                    const int iy = oy * d.stride + ty - d.pad, ix = ox * d.stride + tx - d.pad;
+                    const int iy = oy * d.stride + ty - pady, ix = ox * d.stride + tx - padx;
                     if (okm && iy >= 0 && iy < d.Hl && ix >= 0 && ix < d.Wl) mask |= 1u << (ty * d.kw + tx);
                 }
             a_mask[j] = mask;
-            a_off[j] = ((int64_t)(b * d.Hs + oy * d.stride - d.pad) * d.Ws + (ox * d.stride - d.pad)) * d.Cin + lq * 8;
+            a_off[j] = ((int64_t)(b * d.Hs + oy * d.stride - pady) * d.Ws + (ox * d.stride - padx)) * d.Cin + lq * 8;
         } else {
             m = m < d.M ? m : d.M - 1;      // rows past M are clamped (their outputs are masked)
             a_off[j] = (int64_t)m * d.lda + lq * 8;
@@ -390,7 +403,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 const bool ok = (a_mask[j] >> tap) & 1u;
                 int64_t off;
                 if (resample) {   // Upsample / SPADE-resize convs: source pixel = ((iy >> up) << dn, (ix >> up) << dn)
-                    const int iy = a_oy[j] * d.stride + ky - d.pad, ix = a_ox[j] * d.stride + kx - d.pad;
+                    const int iy = a_oy[j] * d.stride + ky - pady, ix = a_ox[j] * d.stride + kx - padx;
                     const int sy = (iy >> d.up_shift) << d.dn_shift, sx = (ix >> d.up_shift) << d.dn_shift;
                     off = ((int64_t)(a_b[j] * d.Hs + sy) * d.Ws + sx) * d.Cin + kc + lq * 8;
                 } else {
@@ -858,7 +871,7 @@ int launch(const FridoGemm& d, hipStream_t s) {
 bool patch_ok(const FridoGemm& d) {
     if (!d.conv || d.nsplit != 1 || d.batch != 1) return false;
     if (d.splitk > 1 && (!d.ws || d.splitk > ((d.Cin + d.K2) >> 5))) return false;
-    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.up_shift || d.dn_shift) return false;
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.padx != 1 || d.up_shift || d.dn_shift || d.up2_phase) return false;
     if (d.Ho != d.Hs || d.Wo != d.Ws || d.Hl != d.Hs || d.Wl != d.Ws) return false;
     const int W = d.Ws, HW = d.Hs * d.Ws;
     if (W < 8 || W > 64 || (W & (W - 1))) return false;
@@ -961,12 +974,19 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
         FRIDO_REQUIRE(d.K == d.kh * d.kw * d.Cin, "conv K != kh*kw*Cin");
         FRIDO_REQUIRE(d.Ho > 0 && d.Wo > 0 && d.M % (d.Ho * d.Wo) == 0, "conv M must be Bimg*Ho*Wo");
         FRIDO_REQUIRE(d.stride >= 1 && d.up_shift >= 0 && d.dn_shift >= 0, "bad conv geometry");
-        FRIDO_REQUIRE(d.batch == 1, "conv mode is not batched");
+        FRIDO_REQUIRE(d.batch == 1 || d.up2_phase == 5, "conv mode is not batched (except the four upsample phases)");
     } else {
         FRIDO_REQUIRE((d.lda & 7) == 0 && (d.a_bs & 7) == 0, "A rows must be 16-byte aligned");
     }
     if (d.rowvec) FRIDO_REQUIRE(d.rows_per_vec > 0, "rows_per_vec");
     if (d.batch_inner > 1) FRIDO_REQUIRE(d.batch % d.batch_inner == 0 && !d.residual, "batch must be outer * inner; no residual");
+    if (d.up2_phase) {
+        FRIDO_REQUIRE(d.conv && d.up2_phase >= 1 && d.up2_phase <= 5 && d.splitk <= 1 && !d.residual && !d.rowvec && !d.geglu &&
+                          d.batch == (d.up2_phase == 5 ? 4 : 1) && d.a_bs == 0 && d.of_bs == 0 && d.oo_bs == 0 && d.batch_inner <= 1,
+                      "upsample phase conv: conv only, no split-K / residual / rowvec / geglu; 5 = all four phases as batch 4");
+        FRIDO_REQUIRE((d.Ho & (d.Ho - 1)) == 0 && (d.Wo & (d.Wo - 1)) == 0 && d.M % (d.Ho * d.Wo) == 0 && d.kh == 2 && d.kw == 2,
+                      "upsample phase conv: 2x2 taps, Ho, Wo powers of two");
+    }
     if (d.geglu) {
         FRIDO_REQUIRE((d.N & 31) == 0 && d.out_op && !d.out_f32 && d.batch == 1 && d.splitk <= 1 && !d.residual && !d.rowvec,
                       "geglu epilogue: N % 32 == 0, operand output only, no split-K / residual / rowvec");

@@ -204,6 +204,7 @@ class Prog:
                   of_bs2=of_bs2, oo_bs2=oo_bs2)
         if conv:
             kw.update(conv=1, **conv)
+            kw.setdefault("padx", conv["pad"])
         if A2 is not None:
             kw.update(A2=A2.ptr, a2_lo=A2.lo, lda2=lda2, K2=K2)
         if bias is not None:

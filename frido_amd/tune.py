@@ -54,8 +54,8 @@ _load_cache()
 atexit.register(_save_cache)
 
 _SIG_FIELDS = ("M", "N", "K", "batch", "nsplit", "conv", "lda", "ldb", "a_bs", "b_bs", "Hs", "Ws", "Cin", "Hl", "Wl", "Ho",
-               "Wo", "kh", "kw", "stride", "pad", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
-               "res_bs", "res_bf16", "out_bf16", "batch_inner", "a_bs2", "b_bs2", "of_bs2", "oo_bs2", "K2", "lda2")
+               "Wo", "kh", "kw", "stride", "pad", "padx", "up_shift", "dn_shift", "act", "geglu", "ldo", "ldoo", "of_bs", "oo_bs", "ldr",
+               "res_bs", "res_bf16", "out_bf16", "batch_inner", "a_bs2", "b_bs2", "of_bs2", "oo_bs2", "K2", "lda2", "up2_phase")
 
 
 def _buf(name, nbytes, device):
@@ -96,6 +96,7 @@ def best_tile(st, device, stream):
     t = G()
     C.memmove(C.addressof(t), C.addressof(st), C.sizeof(G))
     ns = st.nsplit
+    t.up2_phase = 0          # timed with in-order output rows: the scratch output is M x N, not the interleaved 4M x N
     if st.conv:
         a_elems = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin
     else:
@@ -131,6 +132,8 @@ def best_tile(st, device, stream):
     nk = (st.K + st.K2) // 32
     small = st.batch == 1 and st.M * st.N <= (1 << 23) and not st.geglu       # split-K only pays for small outputs with a long K
     splits = [1] + [k for k in (2, 3, 4, 6, 8, 12, 16) if small and nk >= 8 * k]
+    if st.up2_phase:
+        splits = [1]          # the split-K reduction writes rows in order; phase convs interleave them
     for sk in splits:
         t.splitk = sk
         t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None

@@ -315,7 +315,7 @@ class UNetStagePlan:
                     nxt = self._spatial_transformer(blk, cur, h, w)
                 elif blk.kind == "up":
                     xo = b.to_operand(cur)
-                    nxt = b.conv(xo, self.Bx, h, w, blk.prefix + ".conv", up=1)
+                    nxt = b.upsample_conv(xo, self.Bx, h, w, blk.prefix + ".conv")
                     xo.free()
                     h, w = h * 2, w * 2
                 cur.free()

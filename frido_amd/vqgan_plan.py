@@ -79,7 +79,7 @@ def vq_run_blocks(b, B, blocks, cur, h, w, keep=()):
             nxt = vq_attn(b, B, blk.prefix, blk.cin, cur, h, w)
         elif blk.kind == "up":       # model.py:49-53
             xo = b.to_operand(cur)
-            nxt = b.conv(xo, B, h, w, blk.prefix + ".conv", up=1)
+            nxt = b.upsample_conv(xo, B, h, w, blk.prefix + ".conv")
             xo.free()
             h, w = h * 2, w * 2
         else:                        # 'down' (model.py:68-72): zero-pad right/bottom by one, conv3x3 stride 2 pad 0

@@ -59,6 +59,13 @@ typedef struct FridoGemm {
     int32_t Hl, Wl;             /* conv: logical (resized) input dims */
     int32_t Ho, Wo;             /* conv: output dims; M = Bimg*Ho*Wo */
     int32_t kh, kw, stride, pad, up_shift, dn_shift;
+    /* asymmetric padding and output-row interleave, used by the 2x2 PHASE convolutions that replace "nearest x2 upsample ->
+       conv3x3" (pyunet.py:110-121, taming model.py:49-53): output pixel (2y+a, 2x+b) only sees a 2x2 source window with
+       summed taps, so four K = 4 Cin GEMMs do 4/9 of the work of one K = 9 Cin GEMM on the upsampled plane.
+       padx: left padding (pad is the top padding); up2_phase = 0: rows are written in order; 1 + 2a + b: row m = (img, y, x)
+       of this GEMM goes to row (img, 2y + a, 2x + b) of a [Bimg][2 Ho][2 Wo] output (Ho, Wo powers of two); 5: all four phases in one launch -- batch = 4, phase = batch
+       index, B holds the four phase weight matrices b_bs apart, pad / padx are ignored (1 - a, 1 - b). */
+    int32_t padx, up2_phase;
     /* optional second A operand appended along K: k in [K, K + K2) reads the dense matrix A2[m][k - K] (lda2).  Used to
        fold the ResBlock's 1x1 skip conv (pyunet.py:248,300; taming model.py:131-135) into the second 3x3 conv. */
     const frido_bf16* A2; int64_t a2_lo; int32_t lda2, K2;

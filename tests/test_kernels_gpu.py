@@ -181,6 +181,27 @@ def test_conv(nsplit, case):
     assert _relerr(got, ref) < _tol(nsplit)
 
 
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 96), (3, 16, 32, 32, 192), (1, 64, 64, 96, 40), (2, 4, 4, 40, 64)])
+def test_upsample_conv_as_phase_convs(nsplit, B, H, W, Cin, Cout):
+    """Upsample = nearest x2 + conv3x3 (pyunet.py:110-121) as four 2x2 phase convolutions with summed taps, written
+    interleaved into the (2H, 2W) plane -- against F.interpolate + F.conv2d and against the 9-tap kernel path."""
+    x = _t("ux", B, Cin, H, W)
+    w = _t("uw", Cout, Cin, 3, 3) / np.sqrt(Cin * 9)
+    bias = _t("ub", Cout)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    b = _builder(nsplit, {"c.weight": w.cuda(), "c.bias": bias.cuda()})
+    xd = x.cuda()
+    a = b.pack(xd.data_ptr(), B, H * W, Cin, 0, Cin, nchw=True)
+    out = b.conv_up2(a, B, H, W, "c")
+    out9 = b.conv(a, B, H, W, "c", up=1)
+    _run(b)
+    got = out.to_f32().cpu().view(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    got9 = out9.to_f32().cpu().view(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert _relerr(got, ref) < _tol(nsplit)
+    assert _relerr(got, got9) < _tol(nsplit)
+
+
 PATCH_CASES = [   # B, H, W, Cin, Cout, Cskip (0 = no fused 1x1 skip operand)
     (4, 64, 64, 64, 192, 0),     # one group = 4 image rows
     (2, 32, 32, 96, 384, 0),     # 8 rows per tile, two N tiles
