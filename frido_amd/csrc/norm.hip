@@ -144,13 +144,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         const frido_bf16* xb2 = reinterpret_cast<const frido_bf16*>(d.x2);
         const frido_bf16* gb = reinterpret_cast<const frido_bf16*>(d.gamma);
         const frido_bf16* bb = reinterpret_cast<const frido_bf16*>(d.beta);
-        for (unsigned i = blockIdx.x * 256u + t; i < total8; i += gridDim.x * 256u) {
+        // two independent vectors per iteration (the x, gamma, beta loads of both are issued before either is consumed)
+        auto one = [&](unsigned i, u32x4& xv, u32x4& gv, u32x4& bv, int64_t& o, int& c) {
             const unsigned p = i / C8;
-            const int c = (int)(i - p * C8) * 8;
+            c = (int)(i - p * C8) * 8;
             const int64_t pix = (int64_t)b * d.HW + p;
-            const int64_t o = pix * C + c;
-            const u32x4 xv = c < d.C1 ? *reinterpret_cast<const u32x4*>(xb1 + pix * d.C1 + c)
-                                      : *reinterpret_cast<const u32x4*>(xb2 + pix * d.C2 + (c - d.C1));
+            o = pix * C + c;
+            xv = c < d.C1 ? *reinterpret_cast<const u32x4*>(xb1 + pix * d.C1 + c)
+                          : *reinterpret_cast<const u32x4*>(xb2 + pix * d.C2 + (c - d.C1));
+            if (d.gamma) {
+                gv = *reinterpret_cast<const u32x4*>(gb + o);
+                bv = *reinterpret_cast<const u32x4*>(bb + o);
+            }
+        };
+        auto fin = [&](const u32x4& xv, const u32x4& gv, const u32x4& bv, int64_t o, int c) {
             float y[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -158,8 +165,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
                 y[2 * e + 1] = fmaf(__uint_as_float(xv[e] & 0xffff0000u), s_sc[c + 2 * e + 1], s_sh[c + 2 * e + 1]);
             }
             if (d.gamma) {
-                const u32x4 gv = *reinterpret_cast<const u32x4*>(gb + o);
-                const u32x4 bv = *reinterpret_cast<const u32x4*>(bb + o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     y[2 * e] = fmaf(y[2 * e], 1.f + __uint_as_float(gv[e] << 16), __uint_as_float(bv[e] << 16));
@@ -175,6 +180,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
             for (int e = 0; e < 4; ++e) ov[e] = f32_to_bf16_bits(y[2 * e]) | (f32_to_bf16_bits(y[2 * e + 1]) << 16);
             *reinterpret_cast<u32x4*>(d.out_op + o) = ov;
             if (d.raw_op) *reinterpret_cast<u32x4*>(d.raw_op + o) = xv;       // concatenated raw operand for the 1x1 skip conv
+        };
+        const unsigned stride = gridDim.x * 256u;
+        unsigned i = blockIdx.x * 256u + t;
+        constexpr int U = 2;
+        for (; i + (U - 1) * stride < total8; i += U * stride) {
+            u32x4 xs[U], gs[U], bs[U];
+            int64_t os[U];
+            int cs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(i + u * stride, xs[u], gs[u], bs[u], os[u], cs[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) fin(xs[u], gs[u], bs[u], os[u], cs[u]);
+        }
+        for (; i < total8; i += stride) {
+            u32x4 x0, g0, b0;
+            int64_t o0;
+            int c0;
+            one(i, x0, g0, b0, o0, c0);
+            fin(x0, g0, b0, o0, c0);
         }
         return;
     }
