@@ -370,12 +370,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
         const int C8 = d.C >> 3;
         const frido_bf16* xb = reinterpret_cast<const frido_bf16*>(d.x) + (int64_t)row * d.C;
         float x[2][8];
+        float4 w4[2][2], b4[2][2];      // affine parameters: fetched now, under the two reductions
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c8 = lane + i * 64;
             if (c8 < C8) {
                 const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + c8 * 8);
+                w4[i][0] = *reinterpret_cast<const float4*>(d.weight + c8 * 8); w4[i][1] = *reinterpret_cast<const float4*>(d.weight + c8 * 8 + 4);
+                b4[i][0] = *reinterpret_cast<const float4*>(d.bias + c8 * 8); b4[i][1] = *reinterpret_cast<const float4*>(d.bias + c8 * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { x[i][2 * e] = __uint_as_float(xv[e] << 16); x[i][2 * e + 1] = __uint_as_float(xv[e] & 0xffff0000u); }
             } else {
@@ -399,11 +402,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
             const int c8 = lane + i * 64;
             if (c8 < C8) {
                 u32x4 ov;
+                const float wv[8] = {w4[i][0].x, w4[i][0].y, w4[i][0].z, w4[i][0].w, w4[i][1].x, w4[i][1].y, w4[i][1].z, w4[i][1].w};
+                const float bv[8] = {b4[i][0].x, b4[i][0].y, b4[i][0].z, b4[i][0].w, b4[i][1].x, b4[i][1].y, b4[i][1].z, b4[i][1].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c = c8 * 8 + 2 * e;
-                    const float y0 = (x[i][2 * e] - mean) * rstd * d.weight[c] + d.bias[c];
-                    const float y1 = (x[i][2 * e + 1] - mean) * rstd * d.weight[c + 1] + d.bias[c + 1];
+                    const float y0 = (x[i][2 * e] - mean) * rstd * wv[2 * e] + bv[2 * e];
+                    const float y1 = (x[i][2 * e + 1] - mean) * rstd * wv[2 * e + 1] + bv[2 * e + 1];
                     ov[e] = f32_to_bf16_bits(y0) | (f32_to_bf16_bits(y1) << 16);
                 }
                 *reinterpret_cast<u32x4*>(d.out_op + (int64_t)row * d.C + c8 * 8) = ov;
