@@ -128,51 +128,60 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         const float4 t0 = *reinterpret_cast<const float4*>(d.bias + ncol), t1 = *reinterpret_cast<const float4*>(d.bias + ncol + 4);
         bia[0] = t0.x; bia[1] = t0.y; bia[2] = t0.z; bia[3] = t0.w; bia[4] = t1.x; bia[5] = t1.y; bia[6] = t1.z; bia[7] = t1.w;
     }
+    // GEGLU (attention.py:42-44): the projection's rows are packed so that 16-column blocks alternate [a | gate]; a value and
+    // its gate are then the SAME element of adjacent accumulator fragments, so a * gelu(gate) is formed in registers and only
+    // the WC/2 outputs go through the LDS transposition (half the slab traffic of transposing both).
+    float gba[TN / 2 > 0 ? TN / 2 : 1], gbg[TN / 2 > 0 ? TN / 2 : 1];
+    if (d.geglu) {
+#pragma unroll
+        for (int jo = 0; jo < TN / 2; ++jo) {
+            const int n = nbase + jo * 32 + col_l;
+            gba[jo] = d.bias && n + 16 < d.N ? d.bias[n] : 0.f;
+            gbg[jo] = d.bias && n + 16 < d.N ? d.bias[n + 16] : 0.f;
+        }
+    }
     for (int i = 0; i < TM; ++i) {
         // static accumulator indices only: if the compiler keeps this (large) loop rolled, acc[i] with a dynamic i would
         // move the whole accumulator tile to scratch
+        f32x4 sel[TN];                   // this slab's accumulators, picked with static indices (see above)
 #pragma unroll
         for (int ii = 0; ii < TM; ++ii)
             if (ii == i) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = acc[ii][j][e];
+                for (int j = 0; j < TN; ++j) sel[j] = acc[ii][j];
             }
-        if (d.geglu) {       // 16-column blocks alternate [a | gate] (attention.py:42-44): every lane makes 8 outputs
-            constexpr int LPRG = WC / 16, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16;
-            const int gr = lane / LPRG, gc = (lane - gr * LPRG) * 8;          // row, first OUTPUT column of this lane
-            const int ac = (gc >> 4) * 32 + (gc & 15);                        // column of `a` inside the wave's slab
-            const int n = nbase + ac;
-            float ba[8], bg[8];
+        if (d.geglu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ba[e] = bg[e] = 0.f;
-            if (d.bias && lane < RPPG * LPRG && n + 16 < d.N) {
-                const float4 t0 = *reinterpret_cast<const float4*>(d.bias + n), t1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
-                const float4 u0 = *reinterpret_cast<const float4*>(d.bias + n + 16), u1 = *reinterpret_cast<const float4*>(d.bias + n + 20);
-                ba[0] = t0.x; ba[1] = t0.y; ba[2] = t0.z; ba[3] = t0.w; ba[4] = t1.x; ba[5] = t1.y; ba[6] = t1.z; ba[7] = t1.w;
-                bg[0] = u0.x; bg[1] = u0.y; bg[2] = u0.z; bg[3] = u0.w; bg[4] = u1.x; bg[5] = u1.y; bg[6] = u1.z; bg[7] = u1.w;
-            }
+            for (int jo = 0; jo < TN / 2; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ep[(row_l + e) * EPS + jo * 16 + col_l] = fmaf(sel[2 * jo][e], d.alpha, gba[jo]) * gelu_f(fmaf(sel[2 * jo + 1][e], d.alpha, gbg[jo]));
+            constexpr int OC = WC / 2;                                        // output columns of this wave
+            constexpr int LPRG = OC / 8, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16;
+            const int gr = lane / LPRG, oc = (lane - gr * LPRG) * 8;          // row, first output column of this lane
+            const int no = (nbase >> 1) + oc;
 #pragma unroll 1
             for (int ps = 0; ps < 16; ps += RPPG) {
                 const int r = ps + gr;
                 const int m = m0 + wm * WR + i * 16 + r;
-                if (lane >= RPPG * LPRG || r >= 16 || m >= d.M || n + 16 >= d.N) continue;
-                const float* sa = ep + r * EPS + ac;
-                const float4 a0 = *reinterpret_cast<const float4*>(sa), a1 = *reinterpret_cast<const float4*>(sa + 4);
-                const float4 g0 = *reinterpret_cast<const float4*>(sa + 16), g1 = *reinterpret_cast<const float4*>(sa + 20);
-                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                if (lane >= RPPG * LPRG || r >= 16 || m >= d.M || no + 7 >= (d.N >> 1)) continue;
+                const float* sa = ep + r * EPS + oc;
+                const float4 o0 = *reinterpret_cast<const float4*>(sa), o1 = *reinterpret_cast<const float4*>(sa + 4);
+                const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
                 uint32_t h[8], l[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_bf16(fmaf(av[e], d.alpha, ba[e]) * gelu_f(fmaf(gv[e], d.alpha, bg[e])), h[e], l[e]);
-                frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + (n >> 5) * 16 + (n & 15);
+                for (int e = 0; e < 8; ++e) split_bf16(ov[e], h[e], l[e]);
+                frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + no;
                 *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 if (d.nsplit == 2)
                     *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
             continue;
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = sel[j][e];
         if (!fast) {
             // generic element-wise path (ragged N or unaligned strides: the 3-channel output conv, odd test shapes).  Rolled
             // and scalar on purpose: unrolled per-element fallbacks inside the vector path tripled the kernel's code size.
