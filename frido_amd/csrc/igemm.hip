@@ -19,6 +19,7 @@
 //  * fused epilogue: alpha, bias[n], per-row bias, per-row-group vector (timestep embedding), ReLU/SiLU,
 //    residual, f32 and/or operand (bf16 hi/lo) output.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -968,6 +969,19 @@ int frido_igemm_init() {
     return rc ? FRIDO_EHIP : FRIDO_OK;
 }
 
+// The > 64 KiB dynamic-LDS opt-in is a per-device function attribute: frido_init() sets it on the device that is current at
+// load time; any other device of the process gets it on its first GEMM.
+static int ensure_device_attrs() {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FRIDO_EHIP;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return FRIDO_OK;
+    const int rc = frido_igemm_init();
+    if (rc == FRIDO_OK) done.fetch_or(bit, std::memory_order_release);
+    return rc;
+}
+
 extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     FRIDO_REQUIRE(dp != nullptr, "null descriptor");
     const FridoGemm& d = *dp;
@@ -1004,6 +1018,7 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
         FRIDO_REQUIRE(d.splitk <= ((d.K + d.K2) >> 6), "more K slices than k-tiles");
     }
+    if (const int arc = ensure_device_attrs()) return arc;
     const int tile = d.tile ? d.tile : pick_tile(d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d.nsplit == 1) return d.conv ? dispatch_tile<1, true>(d, tile, s) : dispatch_tile<1, false>(d, tile, s);
