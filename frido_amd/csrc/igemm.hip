@@ -20,6 +20,7 @@
 //    residual, f32 and/or operand (bf16 hi/lo) output.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -541,6 +542,14 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 //   k-walk: for every 32-channel chunk: 9 taps; then the chunks of the optional second operand A2 (fused 1x1 skip conv,
 //   centre tap only).  vmcnt: loads retire in order, so "stage landed" = at most (pieces issued after it) outstanding; the
 //   per-wave issue counter and the marks of the DB-1 youngest weight stages / two patches live in SGPRs.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int BN>
 struct PGeo {
     static constexpr int BM = 256, NW = 8, NT = 512, WM = 4;
@@ -560,6 +569,120 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n = loads that may 
 #undef W_
         default: wait_vmcnt<32>(); break;
     }
+}
+
+// ---- statically scheduled main loop of the patch kernel (no appended operand) -------------------------------------------
+// The nine taps of a 32-channel chunk are unrolled: tap shifts, weight-stage indices (3-stage ring, stage = tap % 3) and every
+// vmcnt / lgkmcnt immediate are compile-time constants (the dynamic bookkeeping of the general loop -- issue counters, wait
+// switch, k-walk -- was ~40 % of its step time).  (Prefetching the next tap's A fragments into a second register set was tried:
+// with 96 accumulator VGPRs it spills, and every reload sits behind a vmcnt(0) that drains the weight DMA ring.)
+template <int BN>
+struct PatchCtx {
+    unsigned char* smem;
+    const frido_bf16* Ab;
+    const frido_bf16* Bb;
+    int pix[4];
+    int64_t b_off[2];
+    int sbase[4];
+    int pq, cin, PW, wave, kg;
+    unsigned lds0, b_frag;
+    unsigned long long zero_addr;
+};
+
+template <int BN>
+__device__ __forceinline__ void patch_issue_patch(const PatchCtx<BN>& cx, int c, int pb) {
+    using P = PGeo<BN>;
+    const frido_bf16* base = cx.Ab + c * 32 + cx.pq;
+    unsigned char* dst = cx.smem + pb * P::PBUF + cx.wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int px = cx.pix[j];
+        asm volatile("" : "+v"(px));
+        const frido_bf16* src = px >= 0 ? base + (int64_t)px * cx.cin : reinterpret_cast<const frido_bf16*>(cx.zero_addr);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 8192), 16, 0, 0);
+    }
+}
+
+template <int BN>
+__device__ __forceinline__ void patch_issue_b(const PatchCtx<BN>& cx, int c, int tap, int stage) {
+    using P = PGeo<BN>;
+    const int64_t koff = (int64_t)tap * cx.cin + c * 32;
+    unsigned char* dst = cx.smem + P::B0 + stage * P::BSTAGE + cx.wave * 1024;
+    int64_t bo0 = cx.b_off[0], bo1 = cx.b_off[1];
+    asm volatile("" : "+v"(bo0), "+v"(bo1));                    // no per-tap copies of these hoisted out of the chunk loop
+    __builtin_amdgcn_global_load_lds((gptr_t)(cx.Bb + bo0 + koff), (lptr_t)dst, 16, 0, 0);
+    if (cx.wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)(cx.Bb + bo1 + koff), (lptr_t)(dst + 8192), 16, 0, 0);
+}
+
+template <int BN, int TAP>
+__device__ __forceinline__ void patch_read_a(const PatchCtx<BN>& cx, bf16x8 (&fa)[4], int c) {
+    using P = PGeo<BN>;
+    // The addresses are recomputed at every tap ON PURPOSE (the empty asm makes the inputs opaque): left alone, hipcc hoists
+    // all 36 + 18 (tap, fragment) LDS addresses out of the chunk loop, spills them, and reloads each one behind a vmcnt(0).
+    int pw = cx.PW;
+    asm volatile("" : "+s"(pw));
+    const int shift = (TAP / 3 - 1) * pw + (TAP % 3 - 1);
+    const unsigned pbase = cx.lds0 + (c & 1) * P::PBUF + (cx.kg << 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int sb = cx.sbase[i];
+        asm volatile("" : "+v"(sb));
+        const int sl = sb + shift;
+        fa[i] = lds_read128((pbase + (sl << 6)) ^ ((sl & 4) << 3));
+    }
+}
+
+template <int BN, int T, bool LAST>
+__device__ __forceinline__ void patch_tap(const PatchCtx<BN>& cx, f32x4 (&acc)[4][BN / 32], int c) {
+    using P = PGeo<BN>;
+    constexpr int TM = 4, TN = BN / 32;
+    // loads issued after the weight stage of tap T (in-order retirement): the next tap's stage, plus the next chunk's patch when
+    // it was issued in between (taps 1 and 2 of a non-final chunk)
+    constexpr int NEXT = (LAST && T == 8) ? 0 : 1;
+    constexpr int PATCH = (!LAST && (T == 1 || T == 2)) ? 4 : 0;
+    if (cx.wave < 4) wait_vmcnt<2 * NEXT + PATCH>();
+    else wait_vmcnt<NEXT + PATCH>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (T + 2 <= 8) patch_issue_b<BN>(cx, c, T + 2, (T + 2) % 3);
+    else if constexpr (!LAST) patch_issue_b<BN>(cx, c + 1, T - 7, (T + 2) % 3);
+    if constexpr (T == 0 && !LAST) patch_issue_patch<BN>(cx, c + 1, (c + 1) & 1);
+    bf16x8 fa[4];
+    patch_read_a<BN, T>(cx, fa, c);
+    unsigned sbb = cx.b_frag;
+    asm volatile("" : "+v"(sbb));                               // see patch_read_a: keep the fragment addresses from being hoisted
+    sbb += (T % 3) * P::BSTAGE;
+    bf16x8 fb[2];
+    fb[0] = lds_read128(sbb);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if (j + 1 < TN) {
+            fb[(j + 1) & 1] = lds_read128(sbb + (j + 1) * 16 * 64);
+            asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j & 1], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int BN, bool LAST>
+__device__ __forceinline__ void patch_chunk(const PatchCtx<BN>& cx, f32x4 (&acc)[4][BN / 32], int c) {
+    patch_tap<BN, 0, LAST>(cx, acc, c); patch_tap<BN, 1, LAST>(cx, acc, c); patch_tap<BN, 2, LAST>(cx, acc, c);
+    patch_tap<BN, 3, LAST>(cx, acc, c); patch_tap<BN, 4, LAST>(cx, acc, c); patch_tap<BN, 5, LAST>(cx, acc, c);
+    patch_tap<BN, 6, LAST>(cx, acc, c); patch_tap<BN, 7, LAST>(cx, acc, c); patch_tap<BN, 8, LAST>(cx, acc, c);
+}
+
+template <int BN>
+__device__ __forceinline__ void patch_static_loop(const PatchCtx<BN>& cx, f32x4 (&acc)[4][BN / 32], int c_begin, int nch) {
+    // prologue: patch + two weight stages in flight
+    patch_issue_patch<BN>(cx, c_begin, c_begin & 1);
+    patch_issue_b<BN>(cx, c_begin, 0, 0);
+    patch_issue_b<BN>(cx, c_begin, 1, 1);
+    for (int c = c_begin; c + 1 < nch; ++c) patch_chunk<BN, false>(cx, acc, c);
+    if (c_begin < nch) patch_chunk<BN, true>(cx, acc, nch - 1);
 }
 
 template <int BN>
@@ -666,6 +789,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     }
     const unsigned b_frag = lds0 + P::B0 + (wn * (BN / 2) + frow) * 64 + ((kg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
 
+    if (nc2 == 0) {
+        PatchCtx<BN> cx{smem, Ab, Bb, {pix[0], pix[1], pix[2], pix[3]}, {b_off[0], b_off[1]}, {sbase[0], sbase[1], sbase[2], sbase[3]},
+                        pq, cin, PW, wave, kg, lds0, b_frag, zero_addr};
+        patch_static_loop<BN>(cx, acc, c_begin, nch);
+        tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
+        return;
+    }
     // ---- prologue ----
     int tot = 0;                      // DMA pieces this wave has issued
     issue_patch(c_begin, c_begin & 1);
