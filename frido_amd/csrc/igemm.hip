@@ -550,14 +550,18 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BN>
+// NW = 8: 256 x 192 tile (one workgroup per CU);  NW = 4: 128 x 192 tile (two per CU) for the planes where 256-row tiles
+// would leave CUs idle.  Both: wave tile 64 x 96, 12 weight chunks of 1 KiB per tap dealt round-robin to the waves.
+template <int BN, int NW_>
 struct PGeo {
-    static constexpr int BM = 256, NW = 8, NT = 512, WM = 4;
-    static constexpr int PBUF = 32 * 1024, BSTAGE = BN * 64, DB = 6;
+    static constexpr int NW = NW_, BM = NW * 32, NT = NW * 64, WM = NW / 2;
+    static constexpr int PCH = NW * 4;                       // 1-KiB chunks (16 pixel slots) per patch buffer: 4 per wave
+    static constexpr int PBUF = PCH * 1024, BSTAGE = BN * 64, DB = NW == 8 ? 6 : 3;
+    static constexpr int BCH = BN / 16, LPBMAX = (BCH + NW - 1) / NW;   // weight chunks per tap; pieces per wave (upper bound)
     static constexpr int B0 = 2 * PBUF;
     static constexpr int EPI = NW * 16 * (BN / 2 + 4) * 4;
     static constexpr int SMEM = B0 + DB * BSTAGE > EPI ? B0 + DB * BSTAGE : EPI;
-    static_assert(BN == 192, "weight-stage DMA split assumes 12 chunks: 8 + 4");
+    static_assert(BN == 192 && (NW == 8 || NW == 4), "12 weight chunks: 8 + 4 (8 waves) or 3 x 4 (4 waves)");
     static_assert(SMEM <= 163840, "LDS budget");
 };
 
@@ -576,22 +580,22 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n = loads that may 
 // vmcnt / lgkmcnt immediate are compile-time constants (the dynamic bookkeeping of the general loop -- issue counters, wait
 // switch, k-walk -- was ~40 % of its step time).  (Prefetching the next tap's A fragments into a second register set was tried:
 // with 96 accumulator VGPRs it spills, and every reload sits behind a vmcnt(0) that drains the weight DMA ring.)
-template <int BN>
+template <int BN, int NW>
 struct PatchCtx {
     unsigned char* smem;
     const frido_bf16* Ab;
     const frido_bf16* Bb;
     int pix[4];
-    int64_t b_off[2];
+    int64_t b_off[PGeo<BN, NW>::LPBMAX];
     int sbase[4];
     int pq, cin, PW, wave, kg;
     unsigned lds0, b_frag;
     unsigned long long zero_addr;
 };
 
-template <int BN>
-__device__ __forceinline__ void patch_issue_patch(const PatchCtx<BN>& cx, int c, int pb) {
-    using P = PGeo<BN>;
+template <int BN, int NW>
+__device__ __forceinline__ void patch_issue_patch(const PatchCtx<BN, NW>& cx, int c, int pb) {
+    using P = PGeo<BN, NW>;
     const frido_bf16* base = cx.Ab + c * 32 + cx.pq;
     unsigned char* dst = cx.smem + pb * P::PBUF + cx.wave * 1024;
 #pragma unroll
@@ -599,24 +603,27 @@ __device__ __forceinline__ void patch_issue_patch(const PatchCtx<BN>& cx, int c,
         int px = cx.pix[j];
         asm volatile("" : "+v"(px));
         const frido_bf16* src = px >= 0 ? base + (int64_t)px * cx.cin : reinterpret_cast<const frido_bf16*>(cx.zero_addr);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * (NW * 1024)), 16, 0, 0);
     }
 }
 
-template <int BN>
-__device__ __forceinline__ void patch_issue_b(const PatchCtx<BN>& cx, int c, int tap, int stage) {
-    using P = PGeo<BN>;
+template <int BN, int NW>
+__device__ __forceinline__ void patch_issue_b(const PatchCtx<BN, NW>& cx, int c, int tap, int stage) {
+    using P = PGeo<BN, NW>;
     const int64_t koff = (int64_t)tap * cx.cin + c * 32;
     unsigned char* dst = cx.smem + P::B0 + stage * P::BSTAGE + cx.wave * 1024;
-    int64_t bo0 = cx.b_off[0], bo1 = cx.b_off[1];
-    asm volatile("" : "+v"(bo0), "+v"(bo1));                    // no per-tap copies of these hoisted out of the chunk loop
-    __builtin_amdgcn_global_load_lds((gptr_t)(cx.Bb + bo0 + koff), (lptr_t)dst, 16, 0, 0);
-    if (cx.wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)(cx.Bb + bo1 + koff), (lptr_t)(dst + 8192), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < P::LPBMAX; ++j) {
+        int64_t bo = cx.b_off[j];
+        asm volatile("" : "+v"(bo));                            // no per-tap copies of these hoisted out of the chunk loop
+        if (cx.wave + NW * j < P::BCH)
+            __builtin_amdgcn_global_load_lds((gptr_t)(cx.Bb + bo + koff), (lptr_t)(dst + j * (NW * 1024)), 16, 0, 0);
+    }
 }
 
-template <int BN, int TAP>
-__device__ __forceinline__ void patch_read_a(const PatchCtx<BN>& cx, bf16x8 (&fa)[4], int c) {
-    using P = PGeo<BN>;
+template <int BN, int NW, int TAP>
+__device__ __forceinline__ void patch_read_a(const PatchCtx<BN, NW>& cx, bf16x8 (&fa)[4], int c) {
+    using P = PGeo<BN, NW>;
     // The addresses are recomputed at every tap ON PURPOSE (the empty asm makes the inputs opaque): left alone, hipcc hoists
     // all 36 + 18 (tap, fragment) LDS addresses out of the chunk loop, spills them, and reloads each one behind a vmcnt(0).
     int pw = cx.PW;
@@ -632,22 +639,26 @@ __device__ __forceinline__ void patch_read_a(const PatchCtx<BN>& cx, bf16x8 (&fa
     }
 }
 
-template <int BN, int T, bool LAST>
-__device__ __forceinline__ void patch_tap(const PatchCtx<BN>& cx, f32x4 (&acc)[4][BN / 32], int c) {
-    using P = PGeo<BN>;
+template <int BN, int NW, int T, bool LAST>
+__device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c) {
+    using P = PGeo<BN, NW>;
     constexpr int TM = 4, TN = BN / 32;
     // loads issued after the weight stage of tap T (in-order retirement): the next tap's stage, plus the next chunk's patch when
     // it was issued in between (taps 1 and 2 of a non-final chunk)
     constexpr int NEXT = (LAST && T == 8) ? 0 : 1;
     constexpr int PATCH = (!LAST && (T == 1 || T == 2)) ? 4 : 0;
-    if (cx.wave < 4) wait_vmcnt<2 * NEXT + PATCH>();
-    else wait_vmcnt<NEXT + PATCH>();
+    if constexpr (NW == 8) {                 // waves 0-3 carry two weight pieces per tap, waves 4-7 one
+        if (cx.wave < 4) wait_vmcnt<2 * NEXT + PATCH>();
+        else wait_vmcnt<NEXT + PATCH>();
+    } else {
+        wait_vmcnt<3 * NEXT + PATCH>();
+    }
     __builtin_amdgcn_s_barrier();
-    if constexpr (T + 2 <= 8) patch_issue_b<BN>(cx, c, T + 2, (T + 2) % 3);
-    else if constexpr (!LAST) patch_issue_b<BN>(cx, c + 1, T - 7, (T + 2) % 3);
-    if constexpr (T == 0 && !LAST) patch_issue_patch<BN>(cx, c + 1, (c + 1) & 1);
+    if constexpr (T + 2 <= 8) patch_issue_b<BN, NW>(cx, c, T + 2, (T + 2) % 3);
+    else if constexpr (!LAST) patch_issue_b<BN, NW>(cx, c + 1, T - 7, (T + 2) % 3);
+    if constexpr (T == 0 && !LAST) patch_issue_patch<BN, NW>(cx, c + 1, (c + 1) & 1);
     bf16x8 fa[4];
-    patch_read_a<BN, T>(cx, fa, c);
+    patch_read_a<BN, NW, T>(cx, fa, c);
     unsigned sbb = cx.b_frag;
     asm volatile("" : "+v"(sbb));                               // see patch_read_a: keep the fragment addresses from being hoisted
     sbb += (T % 3) * P::BSTAGE;
@@ -668,27 +679,27 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN>& cx, f32x4 (&acc)[4
     }
 }
 
-template <int BN, bool LAST>
-__device__ __forceinline__ void patch_chunk(const PatchCtx<BN>& cx, f32x4 (&acc)[4][BN / 32], int c) {
-    patch_tap<BN, 0, LAST>(cx, acc, c); patch_tap<BN, 1, LAST>(cx, acc, c); patch_tap<BN, 2, LAST>(cx, acc, c);
-    patch_tap<BN, 3, LAST>(cx, acc, c); patch_tap<BN, 4, LAST>(cx, acc, c); patch_tap<BN, 5, LAST>(cx, acc, c);
-    patch_tap<BN, 6, LAST>(cx, acc, c); patch_tap<BN, 7, LAST>(cx, acc, c); patch_tap<BN, 8, LAST>(cx, acc, c);
+template <int BN, int NW, bool LAST>
+__device__ __forceinline__ void patch_chunk(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c) {
+    patch_tap<BN, NW, 0, LAST>(cx, acc, c); patch_tap<BN, NW, 1, LAST>(cx, acc, c); patch_tap<BN, NW, 2, LAST>(cx, acc, c);
+    patch_tap<BN, NW, 3, LAST>(cx, acc, c); patch_tap<BN, NW, 4, LAST>(cx, acc, c); patch_tap<BN, NW, 5, LAST>(cx, acc, c);
+    patch_tap<BN, NW, 6, LAST>(cx, acc, c); patch_tap<BN, NW, 7, LAST>(cx, acc, c); patch_tap<BN, NW, 8, LAST>(cx, acc, c);
 }
 
-template <int BN>
-__device__ __forceinline__ void patch_static_loop(const PatchCtx<BN>& cx, f32x4 (&acc)[4][BN / 32], int c_begin, int nch) {
+template <int BN, int NW>
+__device__ __forceinline__ void patch_static_loop(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c_begin, int nch) {
     // prologue: patch + two weight stages in flight
-    patch_issue_patch<BN>(cx, c_begin, c_begin & 1);
-    patch_issue_b<BN>(cx, c_begin, 0, 0);
-    patch_issue_b<BN>(cx, c_begin, 1, 1);
-    for (int c = c_begin; c + 1 < nch; ++c) patch_chunk<BN, false>(cx, acc, c);
-    if (c_begin < nch) patch_chunk<BN, true>(cx, acc, nch - 1);
+    patch_issue_patch<BN, NW>(cx, c_begin, c_begin & 1);
+    patch_issue_b<BN, NW>(cx, c_begin, 0, 0);
+    patch_issue_b<BN, NW>(cx, c_begin, 1, 1);
+    for (int c = c_begin; c + 1 < nch; ++c) patch_chunk<BN, NW, false>(cx, acc, c);
+    if (c_begin < nch) patch_chunk<BN, NW, true>(cx, acc, nch - 1);
 }
 
-template <int BN>
-__global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d) {
-    using P = PGeo<BN>;
-    constexpr int BM = P::BM, NW = P::NW, WM = P::WM, TM = BM / WM / 16, TN = BN / 2 / 16, DB = P::DB;
+template <int BN, int NW>
+__global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_kernel(const FridoGemm d) {
+    using P = PGeo<BN, NW>;
+    constexpr int BM = P::BM, WM = P::WM, TM = BM / WM / 16, TN = BN / 2 / 16, DB = P::DB, LPBMAX = P::LPBMAX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -711,12 +722,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     const int ngrp = BM / RW;
     const int img0 = m0 / HW, y0 = (m0 - img0 * HW) / W;
 
-    // ---- patch DMA pieces of this lane: chunks wave, wave+8, wave+16, wave+24; slot = chunk*16 + lane/4 ----
+    // ---- patch DMA pieces of this lane: chunks wave, wave+NW, wave+2NW, wave+3NW; slot = chunk*16 + lane/4 ----
     const int pq = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 8;      // logical k-piece this lane fetches (elements)
     int pix[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int slot = (wave + 8 * j) * 16 + (lane >> 2);
+        const int slot = (wave + NW * j) * 16 + (lane >> 2);
         const int g = slot / PS, rem = slot - g * PS;
         const int pr = rem / PW, px = rem - pr * PW;
         const int y = y0 + pr - 1, x = px - 1;
@@ -726,11 +737,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     // ---- weight DMA pieces: chunk `wave` (all waves) and chunk 8 + wave (waves 0-3); existing BK = 32 row swizzle ----
     const int lrow = lane >> 2;
     const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
-    const int lpb = wave < 4 ? 2 : 1;
-    int64_t b_off[2];
+    const int lpb = NW == 8 ? (wave < 4 ? 2 : 1) : 3;
+    int64_t b_off[LPBMAX];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int n = n0 + (wave + 8 * j) * 16 + lrow;
+    for (int j = 0; j < LPBMAX; ++j) {
+        int n = n0 + (wave + NW * j) * 16 + lrow;
         n = n < d.N ? n : d.N - 1;
         b_off[j] = (int64_t)n * d.ldb + lq * 8;
     }
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const frido_bf16* src = pix[j] >= 0 ? base + (int64_t)pix[j] * ld : reinterpret_cast<const frido_bf16*>(zero_addr);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * (NW * 1024)), 16, 0, 0);
         }
     };
     // issue-side k-walk (uniform): chunk / tap of the next weight stage to fetch
@@ -764,8 +775,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     auto issue_b = [&](int stage) {
         const int64_t koff = ic < nc1 ? (int64_t)it * cin + ic * 32 : (int64_t)d.K + (ic - nc1) * 32;
         unsigned char* dst = smem + P::B0 + stage * P::BSTAGE + wave * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Bb + b_off[0] + koff), (lptr_t)dst, 16, 0, 0);
-        if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)(Bb + b_off[1] + koff), (lptr_t)(dst + 8192), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < LPBMAX; ++j)
+            if (wave + NW * j < P::BCH)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Bb + b_off[j] + koff), (lptr_t)(dst + j * (NW * 1024)), 16, 0, 0);
         if (ic < nc1 && it < 8) ++it;
         else { ++ic; it = ic < nc1 ? 0 : 4; }
     };
@@ -790,9 +803,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const FridoGemm d
     const unsigned b_frag = lds0 + P::B0 + (wn * (BN / 2) + frow) * 64 + ((kg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
 
     if (nc2 == 0) {
-        PatchCtx<BN> cx{smem, Ab, Bb, {pix[0], pix[1], pix[2], pix[3]}, {b_off[0], b_off[1]}, {sbase[0], sbase[1], sbase[2], sbase[3]},
-                        pq, cin, PW, wave, kg, lds0, b_frag, zero_addr};
-        patch_static_loop<BN>(cx, acc, c_begin, nch);
+        PatchCtx<BN, NW> cx;
+        cx.smem = smem; cx.Ab = Ab; cx.Bb = Bb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cx.pix[j] = pix[j]; cx.sbase[j] = sbase[j]; }
+#pragma unroll
+        for (int j = 0; j < LPBMAX; ++j) cx.b_off[j] = b_off[j];
+        cx.pq = pq; cx.cin = cin; cx.PW = PW; cx.wave = wave; cx.kg = kg; cx.lds0 = lds0; cx.b_frag = b_frag; cx.zero_addr = zero_addr;
+        patch_static_loop<BN, NW>(cx, acc, c_begin, nch);
         tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
         return;
     }
@@ -1008,28 +1026,31 @@ int launch(const FridoGemm& d, hipStream_t s) {
 }
 
 // eligibility of the patch-staged 3x3 kernel (tile id 9)
-bool patch_ok(const FridoGemm& d) {
+bool patch_ok(const FridoGemm& d, int bm) {
     if (!d.conv || d.nsplit != 1 || d.batch != 1) return false;
     if (d.splitk > 1 && (!d.ws || d.splitk > ((d.Cin + d.K2) >> 5))) return false;
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.padx != 1 || d.up_shift || d.dn_shift || d.up2_phase) return false;
     if (d.Ho != d.Hs || d.Wo != d.Ws || d.Hl != d.Hs || d.Wl != d.Ws) return false;
     const int W = d.Ws, HW = d.Hs * d.Ws;
     if (W < 8 || W > 64 || (W & (W - 1))) return false;
-    if (d.M % 256 || !((HW % 256) == 0 || (256 % HW) == 0)) return false;
-    const int RW = HW < 256 ? HW : 256, R = RW / W;
-    if ((256 / RW) * (R + 2) * (W + 2) > 512) return false;
+    if (d.M % bm || !((HW % bm) == 0 || (bm % HW) == 0)) return false;
+    const int RW = HW < bm ? HW : bm, R = RW / W;
+    if (R < 1 || (bm / RW) * (R + 2) * (W + 2) > 2 * bm) return false;      // patch slots: 16 per 1-KiB chunk, 4 chunks per wave
     if ((d.Cin & 31) || (d.K2 & 31) || d.K != 9 * d.Cin || (d.K2 && !d.A2)) return false;
     return true;
 }
 
-int launch_patch(const FridoGemm& d, hipStream_t s) {
-    if (!patch_ok(d)) {
-        frido_set_error("igemm: tile 9 (patch-staged 3x3) does not apply to this convolution");
+int launch_patch(const FridoGemm& d, int nw, hipStream_t s) {
+    const int bm = nw * 32;
+    if (!patch_ok(d, bm)) {
+        frido_set_error("igemm: tile 9 / 10 (patch-staged 3x3) does not apply to this convolution");
         return FRIDO_EINVAL;
     }
-    const int tiles = (d.M / 256) * ((d.N + 191) / 192);
+    const int tiles = (d.M / bm) * ((d.N + 191) / 192);
     const int sk = d.splitk > 1 ? d.splitk : 1;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<192>), dim3(tiles, 1, sk), dim3(512), PGeo<192>::SMEM, s, d);
+    constexpr int smem8 = PGeo<192, 8>::SMEM, smem4 = PGeo<192, 4>::SMEM;
+    if (nw == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<192, 8>), dim3(tiles, 1, sk), dim3(512), smem8, s, d);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<192, 4>), dim3(tiles, 1, sk), dim3(256), smem4, s, d);
     if (sk > 1) {
         launch_splitk_reduce(d, s);
     }
@@ -1047,7 +1068,8 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         default: break;
     }
     if constexpr (NS == 1 && CONV) {
-        if (tile == 9) return launch_patch(d, s);
+        if (tile == 9) return launch_patch(d, 8, s);
+        if (tile == 10) return launch_patch(d, 4, s);
     }
     if constexpr (NS == 1) {      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
         if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);
@@ -1091,8 +1113,10 @@ int frido_igemm_init() {
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
           set_attr<256, 256, 1, false, 32>();
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            PGeo<192>::SMEM) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PGeo<192, 8>::SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PGeo<192, 4>::SMEM) != hipSuccess) {
         frido_set_error("igemm: cannot set dynamic LDS size of the patch kernel");
         rc |= 1;
     }

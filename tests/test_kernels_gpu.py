@@ -242,6 +242,12 @@ def test_conv3x3_patch_staged_kernel(case):
     _run(b)
     got = out.to_f32().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
     assert _relerr(got, ref) < 2e-2
+    # tile 10: the same kernel with 128-row tiles (4 waves)
+    out.view().zero_()
+    b.prog.ops[-1][1].tile = 10
+    _run(b)
+    got10 = out.to_f32().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert _relerr(got10, ref) < 2e-2
     # same op on the ring kernel: the two must agree to accumulation-order noise
     b.prog.ops[-1][1].tile = 2
     _run(b)
@@ -251,10 +257,10 @@ def test_conv3x3_patch_staged_kernel(case):
     from frido_amd import tune
     st = b.prog.ops[-1][1]
     nchunks = (st.Cin + st.K2) // 32
-    for sk in (2, 3):
+    for sk, tl in ((2, 9), (3, 9), (2, 10)):
         if sk > nchunks:
             continue
-        st.tile, st.splitk = 9, sk
+        st.tile, st.splitk = tl, sk
         st.ws = tune.workspace(_dev(), sk * st.M * st.N * 4)
         out.view().zero_()
         _run(b)
