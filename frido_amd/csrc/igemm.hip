@@ -591,6 +591,11 @@ struct PatchCtx {
     int pq, cin, PW, wave, kg;
     unsigned lds0, b_frag;
     unsigned long long zero_addr;
+    // appended dense operand A2 (fused 1x1 skip conv): two 1-KiB pieces per wave of the [BM][32] tile, fragment offsets
+    const frido_bf16* A2b;
+    int arow0, lda2;            // first A2 row this lane fetches (the second is NW * 16 rows further), row stride
+    int Kc, nc2;                // K of the conv part (weights of skip chunk s start at column Kc + 32 s); skip chunks
+    int frow0;                  // wave row base + fragment row of this lane: dense-tile fragment addressing
 };
 
 template <int BN, int NW>
@@ -639,14 +644,39 @@ __device__ __forceinline__ void patch_read_a(const PatchCtx<BN, NW>& cx, bf16x8 
     }
 }
 
-template <int BN, int NW, int T, bool LAST>
+// issue the weight stage and the dense A2 tile of skip chunk sidx (stage sidx % 3, tile slot sidx % 4: slots 0, 1 live in the
+// patch buffer the LAST conv chunk does not use, slots 2, 3 in the other one)
+template <int BN, int NW>
+__device__ __forceinline__ void patch_issue_skip(const PatchCtx<BN, NW>& cx, int sidx, int cl) {
+    using P = PGeo<BN, NW>;
+    const int64_t koff = (int64_t)cx.Kc + sidx * 32;
+    unsigned char* dst = cx.smem + P::B0 + (sidx % 3) * P::BSTAGE + cx.wave * 1024;
+#pragma unroll
+    for (int j = 0; j < P::LPBMAX; ++j) {
+        int64_t bo = cx.b_off[j];
+        asm volatile("" : "+v"(bo));
+        if (cx.wave + NW * j < P::BCH)
+            __builtin_amdgcn_global_load_lds((gptr_t)(cx.Bb + bo + koff), (lptr_t)(dst + j * (NW * 1024)), 16, 0, 0);
+    }
+    const int slot = sidx & 3;
+    unsigned char* ad = cx.smem + (((cl + 1) & 1) ^ (slot >> 1)) * P::PBUF + (slot & 1) * (P::BM * 64) + cx.wave * 1024;
+    int ar = cx.arow0;
+    asm volatile("" : "+v"(ar));                                // recomputed per issue: nothing to keep live across the conv chunks
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(cx.A2b + (int64_t)(ar + j * NW * 16) * cx.lda2 + cx.pq + sidx * 32),
+                                         (lptr_t)(ad + j * (NW * 1024)), 16, 0, 0);
+}
+
+// MODE 0: a conv chunk follows; 1: nothing follows; 2: last conv chunk, skip chunks follow
+template <int BN, int NW, int T, int MODE>
 __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c) {
     using P = PGeo<BN, NW>;
     constexpr int TM = 4, TN = BN / 32;
-    // loads issued after the weight stage of tap T (in-order retirement): the next tap's stage, plus the next chunk's patch when
-    // it was issued in between (taps 1 and 2 of a non-final chunk)
-    constexpr int NEXT = (LAST && T == 8) ? 0 : 1;
-    constexpr int PATCH = (!LAST && (T == 1 || T == 2)) ? 4 : 0;
+    // loads issued after the weight stage of tap T (in-order retirement) may stay in flight: the next tap's stage, plus the next
+    // chunk's patch when it was issued in between (taps 1, 2 of MODE 0), plus the first skip chunk's A2 tile (tap 8 of MODE 2)
+    constexpr int NEXT = (MODE == 1 && T == 8) ? 0 : 1;
+    constexpr int PATCH = (MODE == 0 && (T == 1 || T == 2)) ? 4 : ((MODE == 2 && T == 8) ? 2 : 0);
     if constexpr (NW == 8) {                 // waves 0-3 carry two weight pieces per tap, waves 4-7 one
         if (cx.wave < 4) wait_vmcnt<2 * NEXT + PATCH>();
         else wait_vmcnt<NEXT + PATCH>();
@@ -655,8 +685,9 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&ac
     }
     __builtin_amdgcn_s_barrier();
     if constexpr (T + 2 <= 8) patch_issue_b<BN, NW>(cx, c, T + 2, (T + 2) % 3);
-    else if constexpr (!LAST) patch_issue_b<BN, NW>(cx, c + 1, T - 7, (T + 2) % 3);
-    if constexpr (T == 0 && !LAST) patch_issue_patch<BN, NW>(cx, c + 1, (c + 1) & 1);
+    else if constexpr (MODE == 0) patch_issue_b<BN, NW>(cx, c + 1, T - 7, (T + 2) % 3);
+    else if constexpr (MODE == 2) { if (T - 7 < cx.nc2) patch_issue_skip<BN, NW>(cx, T - 7, c); }
+    if constexpr (T == 0 && MODE == 0) patch_issue_patch<BN, NW>(cx, c + 1, (c + 1) & 1);
     bf16x8 fa[4];
     patch_read_a<BN, NW, T>(cx, fa, c);
     unsigned sbb = cx.b_frag;
@@ -679,24 +710,78 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&ac
     }
 }
 
-template <int BN, int NW, bool LAST>
+template <int BN, int NW, int MODE>
 __device__ __forceinline__ void patch_chunk(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c) {
-    patch_tap<BN, NW, 0, LAST>(cx, acc, c); patch_tap<BN, NW, 1, LAST>(cx, acc, c); patch_tap<BN, NW, 2, LAST>(cx, acc, c);
-    patch_tap<BN, NW, 3, LAST>(cx, acc, c); patch_tap<BN, NW, 4, LAST>(cx, acc, c); patch_tap<BN, NW, 5, LAST>(cx, acc, c);
-    patch_tap<BN, NW, 6, LAST>(cx, acc, c); patch_tap<BN, NW, 7, LAST>(cx, acc, c); patch_tap<BN, NW, 8, LAST>(cx, acc, c);
+    patch_tap<BN, NW, 0, MODE>(cx, acc, c); patch_tap<BN, NW, 1, MODE>(cx, acc, c); patch_tap<BN, NW, 2, MODE>(cx, acc, c);
+    patch_tap<BN, NW, 3, MODE>(cx, acc, c); patch_tap<BN, NW, 4, MODE>(cx, acc, c); patch_tap<BN, NW, 5, MODE>(cx, acc, c);
+    patch_tap<BN, NW, 6, MODE>(cx, acc, c); patch_tap<BN, NW, 7, MODE>(cx, acc, c); patch_tap<BN, NW, 8, MODE>(cx, acc, c);
 }
 
+// the appended dense operand: one k-tile per 32-channel chunk, weight stage s % 3, A2 tile slot s % 4, fetch distance 2
 template <int BN, int NW>
+__device__ __forceinline__ void patch_skip_loop(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int cl) {
+    using P = PGeo<BN, NW>;
+    constexpr int TM = 4, TN = BN / 32;
+    for (int sidx = 0; sidx < cx.nc2; ++sidx) {
+        // in flight after this step's loads: the next step's weight stage + A2 tile (if there is a next step)
+        if (sidx + 1 < cx.nc2) {
+            if constexpr (NW == 8) {
+                if (cx.wave < 4) wait_vmcnt<2 + 2>();
+                else wait_vmcnt<1 + 2>();
+            } else {
+                wait_vmcnt<3 + 2>();
+            }
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (sidx + 2 < cx.nc2) patch_issue_skip<BN, NW>(cx, sidx + 2, cl);
+        const int slot = sidx & 3;
+        unsigned abase = cx.lds0 + (((cl + 1) & 1) ^ (slot >> 1)) * P::PBUF + (slot & 1) * (P::BM * 64);
+        bf16x8 fa[4];
+        int fr = cx.frow0;
+        asm volatile("" : "+v"(fr));
+        const unsigned doff = (unsigned)(fr * 64 + ((cx.kg ^ (((fr >> 2) & 1) << 1)) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = lds_read128(abase + doff + i * 16 * 64);
+        const unsigned sbb = cx.b_frag + (sidx % 3) * P::BSTAGE;
+        bf16x8 fb[2];
+        fb[0] = lds_read128(sbb);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (j + 1 < TN) {
+                fb[(j + 1) & 1] = lds_read128(sbb + (j + 1) * 16 * 64);
+                asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j & 1], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int BN, int NW, bool HAS2>
 __device__ __forceinline__ void patch_static_loop(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c_begin, int nch) {
-    // prologue: patch + two weight stages in flight
+    // prologue: patch + two weight stages in flight   (nch = end of the CONV chunks of this workgroup)
     patch_issue_patch<BN, NW>(cx, c_begin, c_begin & 1);
     patch_issue_b<BN, NW>(cx, c_begin, 0, 0);
     patch_issue_b<BN, NW>(cx, c_begin, 1, 1);
-    for (int c = c_begin; c + 1 < nch; ++c) patch_chunk<BN, NW, false>(cx, acc, c);
-    if (c_begin < nch) patch_chunk<BN, NW, true>(cx, acc, nch - 1);
+    for (int c = c_begin; c + 1 < nch; ++c) patch_chunk<BN, NW, 0>(cx, acc, c);
+    if constexpr (HAS2) {
+        if (cx.nc2 > 0) {
+            patch_chunk<BN, NW, 2>(cx, acc, nch - 1);
+            patch_skip_loop<BN, NW>(cx, acc, nch - 1);
+            return;
+        }
+    }
+    patch_chunk<BN, NW, 1>(cx, acc, nch - 1);
 }
 
-template <int BN, int NW>
+// HAS2: instantiated separately for convolutions with an appended operand, so that the plain kernel does not carry its state
+template <int BN, int NW, bool HAS2>
 __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_kernel(const FridoGemm d) {
     using P = PGeo<BN, NW>;
     constexpr int BM = P::BM, WM = P::WM, TM = BM / WM / 16, TN = BN / 2 / 16, DB = P::DB, LPBMAX = P::LPBMAX;
@@ -749,7 +834,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
     const frido_bf16* __restrict__ A2b = d.A2;
     const frido_bf16* __restrict__ Bb = d.B;
     const int cin = d.Cin;
-    const int nc1 = cin >> 5, nc2 = d.K2 >> 5, nch_all = nc1 + nc2;
+    const int nc1 = cin >> 5, nc2 = HAS2 ? d.K2 >> 5 : 0, nch_all = nc1 + nc2;
     // split-K: gridDim.z slices of the 32-channel chunk sequence (a conv chunk = 9 k-tiles, an A2 chunk = 1)
     const int kz = blockIdx.z;
     const int c_begin = (int)((long)nch_all * kz / (int)gridDim.z), nch = (int)((long)nch_all * (kz + 1) / (int)gridDim.z);
@@ -802,7 +887,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
     }
     const unsigned b_frag = lds0 + P::B0 + (wn * (BN / 2) + frow) * 64 + ((kg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
 
-    if (nc2 == 0) {
+    if (nc1 > 0 && (nc2 == 0 || gridDim.z == 1) && c_begin < (nch < nc1 ? nch : nc1)) {
         PatchCtx<BN, NW> cx;
         cx.smem = smem; cx.Ab = Ab; cx.Bb = Bb;
 #pragma unroll
@@ -810,7 +895,9 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
 #pragma unroll
         for (int j = 0; j < LPBMAX; ++j) cx.b_off[j] = b_off[j];
         cx.pq = pq; cx.cin = cin; cx.PW = PW; cx.wave = wave; cx.kg = kg; cx.lds0 = lds0; cx.b_frag = b_frag; cx.zero_addr = zero_addr;
-        patch_static_loop<BN, NW>(cx, acc, c_begin, nch);
+        cx.A2b = A2b; cx.Kc = d.K; cx.nc2 = gridDim.z == 1 ? nc2 : 0;
+        cx.arow0 = m0 + wave * 16 + (lane >> 2); cx.lda2 = d.lda2; cx.frow0 = wm * (BM / WM) + frow;
+        patch_static_loop<BN, NW, HAS2>(cx, acc, c_begin, nch < nc1 ? nch : nc1);
         tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
         return;
     }
@@ -1049,8 +1136,10 @@ int launch_patch(const FridoGemm& d, int nw, hipStream_t s) {
     const int tiles = (d.M / bm) * ((d.N + 191) / 192);
     const int sk = d.splitk > 1 ? d.splitk : 1;
     constexpr int smem8 = PGeo<192, 8>::SMEM, smem4 = PGeo<192, 4>::SMEM;
-    if (nw == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<192, 8>), dim3(tiles, 1, sk), dim3(512), smem8, s, d);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<192, 4>), dim3(tiles, 1, sk), dim3(256), smem4, s, d);
+    if (nw == 8 && d.K2) hipLaunchKernelGGL((conv3x3_patch_kernel<192, 8, true>), dim3(tiles, 1, sk), dim3(512), smem8, s, d);
+    else if (nw == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<192, 8, false>), dim3(tiles, 1, sk), dim3(512), smem8, s, d);
+    else if (d.K2) hipLaunchKernelGGL((conv3x3_patch_kernel<192, 4, true>), dim3(tiles, 1, sk), dim3(256), smem4, s, d);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<192, 4, false>), dim3(tiles, 1, sk), dim3(256), smem4, s, d);
     if (sk > 1) {
         launch_splitk_reduce(d, s);
     }
@@ -1113,9 +1202,13 @@ int frido_igemm_init() {
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
           set_attr<256, 256, 1, false, 32>();
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             PGeo<192, 8>::SMEM) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PGeo<192, 8>::SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PGeo<192, 4>::SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             PGeo<192, 4>::SMEM) != hipSuccess) {
         frido_set_error("igemm: cannot set dynamic LDS size of the patch kernel");
         rc |= 1;
