@@ -555,7 +555,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int BN, int NW_>
 struct PGeo {
     static constexpr int NW = NW_, BM = NW * 32, NT = NW * 64, WM = NW / 2;
-    static constexpr int PCH = NW * 4;                       // 1-KiB chunks (16 pixel slots) per patch buffer: 4 per wave
+    static constexpr int PPW = NW == 8 ? 4 : 5;              // patch pieces (1-KiB chunks of 16 pixel slots) per wave
+    static constexpr int PCH = NW * PPW;                     // chunks per patch buffer: 512 / 320 pixel slots
     static constexpr int PBUF = PCH * 1024, BSTAGE = BN * 64, DB = NW == 8 ? 6 : 3;
     static constexpr int BCH = BN / 16, LPBMAX = (BCH + NW - 1) / NW;   // weight chunks per tap; pieces per wave (upper bound)
     static constexpr int B0 = 2 * PBUF;
@@ -585,7 +586,7 @@ struct PatchCtx {
     unsigned char* smem;
     const frido_bf16* Ab;
     const frido_bf16* Bb;
-    int pix[4];
+    int pix[PGeo<BN, NW>::PPW];
     int64_t b_off[PGeo<BN, NW>::LPBMAX];
     int sbase[4];
     int pq, cin, PW, wave, kg;
@@ -604,7 +605,7 @@ __device__ __forceinline__ void patch_issue_patch(const PatchCtx<BN, NW>& cx, in
     const frido_bf16* base = cx.Ab + c * 32 + cx.pq;
     unsigned char* dst = cx.smem + pb * P::PBUF + cx.wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < P::PPW; ++j) {
         int px = cx.pix[j];
         asm volatile("" : "+v"(px));
         const frido_bf16* src = px >= 0 ? base + (int64_t)px * cx.cin : reinterpret_cast<const frido_bf16*>(cx.zero_addr);
@@ -676,7 +677,7 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&ac
     // loads issued after the weight stage of tap T (in-order retirement) may stay in flight: the next tap's stage, plus the next
     // chunk's patch when it was issued in between (taps 1, 2 of MODE 0), plus the first skip chunk's A2 tile (tap 8 of MODE 2)
     constexpr int NEXT = (MODE == 1 && T == 8) ? 0 : 1;
-    constexpr int PATCH = (MODE == 0 && (T == 1 || T == 2)) ? 4 : ((MODE == 2 && T == 8) ? 2 : 0);
+    constexpr int PATCH = (MODE == 0 && (T == 1 || T == 2)) ? P::PPW : ((MODE == 2 && T == 8) ? 2 : 0);
     if constexpr (NW == 8) {                 // waves 0-3 carry two weight pieces per tap, waves 4-7 one
         if (cx.wave < 4) wait_vmcnt<2 * NEXT + PATCH>();
         else wait_vmcnt<NEXT + PATCH>();
@@ -809,9 +810,9 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
 
     // ---- patch DMA pieces of this lane: chunks wave, wave+NW, wave+2NW, wave+3NW; slot = chunk*16 + lane/4 ----
     const int pq = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 8;      // logical k-piece this lane fetches (elements)
-    int pix[4];
+    int pix[P::PPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < P::PPW; ++j) {
         const int slot = (wave + NW * j) * 16 + (lane >> 2);
         const int g = slot / PS, rem = slot - g * PS;
         const int pr = rem / PW, px = rem - pr * PW;
@@ -850,7 +851,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
         else { base = A2b + (c - nc1) * 32 + pq; ld = d.lda2; }
         unsigned char* dst = smem + pb * P::PBUF + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < P::PPW; ++j) {
             const frido_bf16* src = pix[j] >= 0 ? base + (int64_t)pix[j] * ld : reinterpret_cast<const frido_bf16*>(zero_addr);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * (NW * 1024)), 16, 0, 0);
         }
@@ -891,7 +892,9 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
         PatchCtx<BN, NW> cx;
         cx.smem = smem; cx.Ab = Ab; cx.Bb = Bb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { cx.pix[j] = pix[j]; cx.sbase[j] = sbase[j]; }
+        for (int j = 0; j < P::PPW; ++j) cx.pix[j] = pix[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cx.sbase[j] = sbase[j];
 #pragma unroll
         for (int j = 0; j < LPBMAX; ++j) cx.b_off[j] = b_off[j];
         cx.pq = pq; cx.cin = cin; cx.PW = PW; cx.wave = wave; cx.kg = kg; cx.lds0 = lds0; cx.b_frag = b_frag; cx.zero_addr = zero_addr;
@@ -904,7 +907,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
     // ---- prologue ----
     int tot = 0;                      // DMA pieces this wave has issued
     issue_patch(c_begin, c_begin & 1);
-    tot += 4;
+    tot += P::PPW;
     int markp_cur = tot, markp_nxt = tot;      // issue count right after the current / next chunk's patch
     int mark[DB - 1];                          // ... right after the weight stages of steps s .. s+DB-2
 #pragma unroll
@@ -933,7 +936,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
             newmark = tot;
             if (first && cc + 1 < nch) {
                 issue_patch(cc + 1, (cc + 1) & 1);
-                tot += 4;
+                tot += P::PPW;
                 markp_nxt = tot;
             }
 #pragma unroll
@@ -1122,7 +1125,7 @@ bool patch_ok(const FridoGemm& d, int bm) {
     if (W < 8 || W > 64 || (W & (W - 1))) return false;
     if (d.M % bm || !((HW % bm) == 0 || (bm % HW) == 0)) return false;
     const int RW = HW < bm ? HW : bm, R = RW / W;
-    if (R < 1 || (bm / RW) * (R + 2) * (W + 2) > 2 * bm) return false;      // patch slots: 16 per 1-KiB chunk, 4 chunks per wave
+    if (R < 1 || (bm / RW) * (R + 2) * (W + 2) > (bm == 256 ? 512 : 320)) return false;      // pixel slots of a patch buffer (PGeo::PCH)
     if ((d.Cin & 31) || (d.K2 & 31) || d.K != 9 * d.Cin || (d.K2 && !d.A2)) return false;
     return true;
 }
