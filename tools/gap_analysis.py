@@ -25,14 +25,21 @@ def main():
     rows = rows[last:]
     wall = rows[-1][1] - rows[0][0]
     busy, cur_end, gaps = 0, rows[0][0], []
-    for s, e, _ in rows:
+    before, after, prev = defaultdict(lambda: [0, 0]), defaultdict(lambda: [0, 0]), rows[0][2]
+    for s, e, nm in rows:
         if s > cur_end:
             gaps.append(s - cur_end)
+            if s - cur_end > 2000:            # > 2 us: who is on either side of the bubble?
+                kb = prev.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                ka = nm.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                before[kb][0] += 1; before[kb][1] += s - cur_end
+                after[ka][0] += 1; after[ka][1] += s - cur_end
             busy += e - s
             cur_end = e
         elif e > cur_end:
             busy += e - cur_end
             cur_end = e
+        prev = nm
     per = defaultdict(lambda: [0, 0])
     for s, e, n in rows:
         k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
@@ -43,6 +50,8 @@ def main():
            "idle_frac": (wall - busy) / wall, "sum_dur_ms": sum(e - s for s, e, _ in rows) / 1e6,
            "gap_us_median": gaps[len(gaps) // 2] / 1e3 if gaps else 0, "gap_us_p90": gaps[int(len(gaps) * .9)] / 1e3 if gaps else 0,
            "n_gaps": len(gaps),
+           "bubbles_gt2us_by_preceding_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(before.items(), key=lambda kv: -kv[1][1])[:8]},
+           "bubbles_gt2us_by_following_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(after.items(), key=lambda kv: -kv[1][1])[:8]},
            "per_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}}
     print(json.dumps(out, indent=1))
 
