@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void vq_kernel(const FridoVq d) {
     }
     float best = 3.0e38f;
     int best_j = 0;
-    for (int j0 = 0; j0 < d.n_codes; j0 += VQ_CHUNK) {
+    const bool forced = d.force_idx != nullptr;         // uniform: every thread skips the search (and its barriers)
+    if (forced && ok) {
+        const int64_t f = d.force_idx[pix];
+        best_j = (int)(f < 0 ? 0 : (f >= d.n_codes ? d.n_codes - 1 : f));
+    }
+    for (int j0 = 0; j0 < (forced ? 0 : d.n_codes); j0 += VQ_CHUNK) {
         const int nj = min(VQ_CHUNK, d.n_codes - j0);
         __syncthreads();
         for (int j = t; j < nj; j += 256) {
@@ -157,6 +162,23 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const FridoSamplerSte
     const float dir_c = sqrtf(__fsub_rn(__fsub_rn(1.0f, a_prev), __fmul_rn(sigma, sigma)));
     const uint64_t seed = d.rng_dev ? (uint64_t)d.rng_dev[0] : d.seed;
     const int64_t sample0 = d.rng_dev ? d.rng_dev[1] : d.sample0;
+    const float cfg = d.cfg_dev ? *d.cfg_dev : d.cfg_scale;
+    // PLMS history: explicit pointers, or the 4-slot ring indexed by the device step counter (graph replay)
+    const float* h1 = d.hist1;
+    const float* h2 = d.hist2;
+    const float* h3 = d.hist3;
+    float* eout = d.eps_out;
+    if (d.hist_ring && d.hist_mode) {
+        auto slot = [&](int i) { return d.hist_ring + (int64_t)(i & 3) * d.hist_stride; };
+        if (d.hist_mode == 3) {                 // second half of the Heun-style first step: combine with this step's own e_t
+            h1 = slot(step); h2 = nullptr; h3 = nullptr; eout = nullptr;
+        } else {
+            eout = slot(step);
+            h1 = step >= 1 ? slot(step - 1) : nullptr;
+            h2 = step >= 2 ? slot(step - 2) : nullptr;
+            h3 = step >= 3 ? slot(step - 3) : nullptr;
+        }
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / d.HW, p = i - b * d.HW;
         float nz[12];
@@ -183,14 +205,14 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const FridoSamplerSte
             float e = d.eps_cond[ei];
             if (d.eps_uncond) {
                 const float eu = d.eps_uncond[ei];
-                e = __fadd_rn(eu, __fmul_rn(d.cfg_scale, __fsub_rn(e, eu)));
+                e = __fadd_rn(eu, __fmul_rn(cfg, __fsub_rn(e, eu)));
             }
-            if (d.eps_out) d.eps_out[ei] = e;
-            if (d.hist1) {
+            if (eout) eout[ei] = e;
+            if (h1) {
                 float acc = __fmul_rn(ab0, e);
-                acc = __fadd_rn(acc, __fmul_rn(ab1, d.hist1[ei]));
-                if (d.hist2) acc = __fadd_rn(acc, __fmul_rn(ab2, d.hist2[ei]));
-                if (d.hist3) acc = __fadd_rn(acc, __fmul_rn(ab3, d.hist3[ei]));
+                acc = __fadd_rn(acc, __fmul_rn(ab1, h1[ei]));
+                if (h2) acc = __fadd_rn(acc, __fmul_rn(ab2, h2[ei]));
+                if (h3) acc = __fadd_rn(acc, __fmul_rn(ab3, h3[ei]));
                 e = __fdiv_rn(acc, den);
             }
             if (!d.write_x && !d.pred_x0) continue;
@@ -313,6 +335,13 @@ __global__ void step_add_kernel(const FridoStepAdd d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *d.step += d.delta;
 }
 
+__global__ __launch_bounds__(256) void copy_kernel(const FridoCopy d) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(d.src);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(d.dst);
+    const int64_t n16 = d.n >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(const FridoFill d) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) d.dst[i] = d.value;
 }
@@ -345,6 +374,9 @@ extern "C" int frido_sampler_step(const FridoSamplerStep* d, frido_stream_t s) {
     FRIDO_REQUIRE(d->nch > 0 && d->nch <= 12 && d->start >= 0 && d->start + d->nch <= d->Cx, "bad channel range");
     FRIDO_REQUIRE(!d->write_x || d->x_out, "x_out missing");
     FRIDO_REQUIRE(!d->hist2 || d->hist1, "history must be contiguous");
+    FRIDO_REQUIRE(!d->hist_mode || (d->hist_ring && d->step && d->hist_stride >= (int64_t)d->B * d->HW * d->nch &&
+                                    (d->hist_mode == 1 || d->hist_mode == 3) && !d->hist1 && !d->eps_out),
+                  "hist ring: needs the device step counter, a [4][hist_stride] buffer and no explicit history pointers");
     hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for((int64_t)d->B * d->HW, 2048)), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("sampler_step");
 }
@@ -401,6 +433,13 @@ extern "C" int frido_to_u8(const FridoToU8* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->src && d->dst && d->n > 0, "bad arguments");
     hipLaunchKernelGGL(to_u8_kernel, dim3(grid_for(d->n)), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("to_u8");
+}
+
+extern "C" int frido_copy(const FridoCopy* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->src && d->dst && d->n > 0 && (d->n & 15) == 0 && (((uintptr_t)d->src | (uintptr_t)d->dst) & 15) == 0,
+                  "copy: 16-byte aligned pointers and size");
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(d->n >> 4, 2048)), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("copy");
 }
 
 extern "C" int frido_fill(const FridoFill* d, frido_stream_t s) {

@@ -216,12 +216,14 @@ class VQModelInterface(_Versioned, _Base):
         return self._rt
 
     @torch.no_grad()
-    def decode(self, h_in, force_not_quantize=False, return_code=False, inv_scale=None, to_uint8=False):
+    def decode(self, h_in, force_not_quantize=False, return_code=False, inv_scale=None, to_uint8=False, force_codes=None):
         """msvqgan.py:376-399.  Returns dec (B,3,H,W) [and per-scale code lists when return_code]; to_uint8 returns
         the (B,H,W,3) uint8 image of scripts/sample_diffusion.py:115-121 straight from the decoder's NHWC output."""
         if not h_in.is_cuda:
             _no_cpu("VQModelInterface.decode", h_in.device)
-        out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code, to_uint8=to_uint8)
+        if force_not_quantize:
+            raise NotImplementedError("decode(force_not_quantize=True) is not used by the sampling path")
+        out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code, to_uint8=to_uint8, force_codes=force_codes)
         if return_code:
             dec, idx = out
             return dec, [i.tolist() for i in idx]     # the reference's host lists (msvqgan.py:390)
@@ -280,6 +282,32 @@ class BERTEmbedder(_Versioned, nn.Module):
         plan.prog.run(current_stream_ptr(dev))
         z = plan.out.view(B, n, self.n_embed).clone()
         return (z, tokens) if return_token else z
+
+    def encode(self, text):
+        return self(text)
+
+
+class FrozenCLIPTextEmbedder(nn.Module):
+    """cond_stage_config.target of configs/frido/t2i/frido_f16f8_coco_clip.yaml:80 (reference:
+    frido/modules/encoders/modules.py:188-219: OpenAI CLIP ViT-L/14 text tower -> ONE L2-normalised 768-d token per caption,
+    repeated n_repeat times).  The CLIP package and its weights are not reachable offline (parity
+    unpinned), so the class keeps the constructor / attribute surface and raises a clear error when asked to encode; the
+    t2i path is driven with conditioning tensors (`model.get_learned_conditioning` bypassed) in tests and bench."""
+
+    def __init__(self, version="ViT-L/14", device="cuda", max_length=77, n_repeat=1, normalize=True):
+        super().__init__()
+        self.version, self.device, self.max_length = version, device, max_length
+        self.n_repeat, self.normalize, self.use_tknz_fn = n_repeat, normalize, True
+        self.model = None
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, text):
+        raise NotImplementedError(
+            f"FrozenCLIPTextEmbedder: the OpenAI `clip` package and the '{self.version}' weights are not reachable "
+            "offline; pass the [B, n_repeat, 768] L2-normalised text embedding to the sampler as `conditioning` instead")
 
     def encode(self, text):
         return self(text)
@@ -465,7 +493,8 @@ class FridoDiffusion(_Base):
         return out[0] if isinstance(out, tuple) and not return_ids else out
 
     @torch.no_grad()
-    def decode_first_stage(self, z_in, predict_cids=False, force_not_quantize=False, return_code=False, to_uint8=False):
+    def decode_first_stage(self, z_in, predict_cids=False, force_not_quantize=False, return_code=False, to_uint8=False,
+                           force_codes=None):
         """frido.py:823-891: per-scale 1/scale_factor (fused into the VQ kernel) + first-stage decode."""
         assert not predict_cids
         embed = self.first_stage_model.embed_dim
@@ -475,7 +504,8 @@ class FridoDiffusion(_Base):
         else:
             sfs = self.scale_factor.detach().float().cpu().numpy()
             inv = [float(np.float32(1.0) / np.float32(v)) for v in sfs]
-        return self.first_stage_model.decode(z_in, return_code=return_code, inv_scale=inv, to_uint8=to_uint8)
+        return self.first_stage_model.decode(z_in, return_code=return_code, inv_scale=inv, to_uint8=to_uint8,
+                                             force_codes=force_codes)
 
     @torch.no_grad()
     def encode_first_stage(self, x):
@@ -509,6 +539,31 @@ class FridoDiffusion(_Base):
             out.extend([x, self.decode_first_stage(z)])
         if return_original_cond:
             out.append(xc)
+        return out
+
+    def get_img_ids(self, batch):
+        """frido.py:818-820."""
+        return batch["file_name"]
+
+    @torch.no_grad()
+    def q_sample(self, x_start, t, ch_start=None, ch_end=None, noise=None, mix_tau=0.):
+        """frido.py:302-320: forward diffusion x_t = sqrt(a_t) x_0 + sqrt(1 - a_t) eps, optionally only on the channels
+        [ch_start, ...) of a multi-stage latent (coarser channels kept, channels from ch_end on replaced by noise,
+        optional noise mixing of the kept ones).  A host-side helper of the callers (mask-guided sampling, logging), not on
+        the per-step path: plain tensor arithmetic on whatever device the inputs live on."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        shape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+        a = self.sqrt_alphas_cumprod.to(x_start.device)[t].reshape(shape)
+        s = self.sqrt_one_minus_alphas_cumprod.to(x_start.device)[t].reshape(shape)
+        if ch_start is None:
+            return a * x_start + s * noise
+        out = x_start.clone()
+        out[:, ch_start:] = a * x_start[:, ch_start:] + s * noise[:, ch_start:]
+        if ch_end is not None:
+            out[:, ch_end:] = noise[:, ch_end:]
+        if mix_tau != 0.:
+            out[:, :ch_start] = (1 - mix_tau) * out[:, :ch_start] + mix_tau * noise[:, :ch_start]
         return out
 
     def forward(self, *a, **k):

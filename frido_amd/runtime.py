@@ -82,6 +82,10 @@ class SamplerEngine:
         self.coef = torch.from_numpy(tab).to(self.dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.rng = torch.zeros(2, dtype=torch.int64, device=self.dev)   # {seed, sample0} read by the captured kernels
+        self.cfg_dev = torch.ones(1, dtype=torch.float32, device=self.dev)   # guidance scale read by the captured kernels
+        if not cfg.get("use_split_head", False):
+            raise NotImplementedError("SamplerEngine: the multi-stage loop masks channels per stage, which needs "
+                                      "use_split_head=True (every shipped Frido config)")
         self.x = torch.zeros(B, H * W, C, dtype=torch.float32, device=self.dev)
         self.pred_x0 = torch.zeros_like(self.x)
         self.stages = []
@@ -95,7 +99,8 @@ class SamplerEngine:
         # PLMS state
         if kind == "plms":
             nmax = max(self.embed[:self.num_stage])
-            self.hist = [torch.zeros(B * H * W, nmax, dtype=torch.float32, device=self.dev) for _ in range(4)]
+            self.hist_stride = B * H * W * nmax
+            self.hist = torch.zeros(4, self.hist_stride, dtype=torch.float32, device=self.dev)    # eps ring, slot = step & 3
             self.x_save = torch.zeros_like(self.x)
 
     # ---- helpers ---------------------------------------------------------------------------------
@@ -105,7 +110,7 @@ class SamplerEngine:
         return self._stream
 
     def _sampler_op(self, s, *, noise_ptr, noise_C, seed, sample0, write_x=1, x_out=None, eps_out=None, hist=(),
-                    row_offset=0):
+                    row_offset=0, hist_mode=0):
         plan = self.stages[s]
         start = sum(self.embed[:s])
         nch = self.embed[s]
@@ -114,7 +119,10 @@ class SamplerEngine:
                   eps_cond=plan.eps.data_ptr(), cfg_scale=self.cfg_scale, coef=self.coef.data_ptr(),
                   step=self.step.data_ptr(), coef_row_offset=row_offset, temperature=self.temperature,
                   x_out=(x_out if x_out is not None else self.x.data_ptr()), pred_x0=self.pred_x0.data_ptr(),
-                  write_x=write_x, seed=seed, sample0=sample0, rng_stream=s + 1, rng_dev=self.rng.data_ptr())
+                  write_x=write_x, seed=seed, sample0=sample0, rng_stream=s + 1, rng_dev=self.rng.data_ptr(),
+                  cfg_dev=self.cfg_dev.data_ptr())
+        if hist_mode:
+            kw.update(hist_ring=self.hist.data_ptr(), hist_stride=self.hist_stride, hist_mode=hist_mode)
         if self.xrep == 2:
             kw["eps_uncond"] = plan.eps.data_ptr() + 4 * BHW * nch
         if noise_ptr:
@@ -138,8 +146,10 @@ class SamplerEngine:
     def run(self, cond, uncond=None, *, x_T=None, noise="philox", seed=0, sample0=0, log_every_t=100, callback=None,
             img_callback=None):
         """Runs all stages.  noise: "philox" (device counter RNG), "torch" (draw from torch's global CPU generator in
-        exactly the reference's order — same seeds give the reference's noise stream), or a callable
-        shape -> tensor replaying a recorded tape.  Returns (samples NCHW, intermediates dict)."""
+        exactly the reference's order -- the stream of a reference run on CPU with the same torch.manual_seed), or a
+        callable shape -> tensor replaying a recorded tape.  A supplied x_T is, like in the reference (ddim.py:150-152,
+        plms.py:150-152), taken as the FINISHED stage-0 result: stage 0 and its pooling hand-off are skipped (with one
+        stage x_T comes back unchanged).  Returns (samples NCHW, intermediates dict)."""
         B, C, H, W = self.B, self.C, self.H, self.W
         stream = self._stream_ptr()
         stream.wait_stream(torch.cuda.current_stream(self.dev))
@@ -153,6 +163,7 @@ class SamplerEngine:
             ctx = cond.to(self.dev, torch.float32)
             if self.xrep == 2:
                 ctx = torch.cat([ctx, uncond.to(self.dev, torch.float32)], dim=0)
+            self.cfg_dev.fill_(self.cfg_scale)
             # ---- x_T (ddim.py:127-130) ----
             if x_T is not None:
                 xt = torch.as_tensor(x_T, dtype=torch.float32)
@@ -172,6 +183,8 @@ class SamplerEngine:
             t_loop = torch.from_numpy(self.t_loop.astype(np.int64)).to(self.dev)
             n = self.n_steps
             for s in range(self.num_stage):
+                if x_T is not None and s == 0:
+                    continue                 # ddim.py:150-152: "Auto adopt x_T into stage 0" (no denoising, no hand-off)
                 plan = self.stages[s]
                 Cs = sum(self.embed[:s + 1])
                 plan.set_context(ctx)
@@ -245,50 +258,48 @@ class SamplerEngine:
             self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
 
     def _plms_stage(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs):
-        """plms.py:156-194,285-303: Heun-style first step (two denoiser calls), then Adams-Bashforth 2/3/4."""
+        """plms.py:156-194,285-303: Heun-style first step (two denoiser calls), then Adams-Bashforth 2/3/4.  Two captured
+        hipGraphs per stage serve every step: `first` = [forward, save x, update with e_t (eps -> ring slot 0), step+1,
+        forward at (x_prev, t_next), step-1, restore x, update with (e_t + e_next)/2, step+1]; `body` = [forward, update with
+        the ring history selected by the device step counter, step+1].  eta == 0 (plms.py:25-26), so no noise enters the
+        update and the same graphs serve the philox / torch / tape modes."""
         from .engine import Prog
         plan = self.stages[s]
         n = self.n_steps
-        key = ("plms_fwd", s)
-        fwd = self.graphs.get(key)
-        if fwd is None:
-            fwd = plan.step.capture(sp) if self.use_graph else plan.step
-            self.graphs[key] = fwd
-        go = (lambda: fwd.launch(sp)) if self.use_graph else (lambda: fwd.run(sp))
-        nch = self.embed[s]
-        hist = [h.data_ptr() for h in self.hist]
+        self.rng.copy_(torch.tensor([seed, sample0], dtype=torch.int64))
+        nbytes = self.x.numel() * 4
 
-        def tail(**kw):
+        def build(first):
             p = Prog(self.dev, self.b.nsplit)
-            p.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=seed, sample0=sample0, **kw))
-            return p
+            p.ops = list(plan.step.ops)
+            if first:
+                p.emit("FRIDO_OP_COPY", src=self.x.data_ptr(), dst=self.x_save.data_ptr(), n=nbytes)
+                p.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0, hist_mode=1))
+                if n > 1:
+                    p.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
+                p.ops += list(plan.step.ops)
+                if n > 1:
+                    p.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=-1)
+                p.emit("FRIDO_OP_COPY", src=self.x_save.data_ptr(), dst=self.x.data_ptr(), n=nbytes)
+                p.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0, hist_mode=3))
+            else:
+                p.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0, hist_mode=1))
+            p.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
+            p.keep = [plan]
+            return p.capture(sp) if self.use_graph else p
 
+        for name, first in (("plms_first", True), ("plms_body", False)):
+            if (name, s) not in self.graphs:
+                self.graphs[(name, s)] = build(first)
+        g_first, g_body = self.graphs[("plms_first", s)], self.graphs[("plms_body", s)]
+        go = (lambda g: g.launch(sp)) if self.use_graph else (lambda g: g.run(sp))
         for i in range(n):
-            # eta == 0: the reference still draws (and discards) noise for every update; keep the CPU stream in step
+            # eta == 0: the reference still draws (and discards) noise for every update; keep a replayed stream in step
             if draw is not None:
                 draw((self.B, Cs, self.H, self.W))
-            go()
-            if i == 0:
-                # x_prev with e_t (scratch), e_next = eps(x_prev, t_next), e' = (e_t + e_next) / 2
-                if draw is not None:
+                if i == 0:
                     draw((self.B, Cs, self.H, self.W))
-                self.x_save.copy_(self.x)
-                p = tail(eps_out=hist[0])
-                p.run(sp)                                   # x <- x_prev(e_t); hist[0] <- e_t
-                if n > 1:
-                    _run1(self.b, "FRIDO_OP_STEP_ADD", sp, step=self.step.data_ptr(), delta=1)
-                go()                                        # eps(x_prev, t_next)
-                if n > 1:
-                    _run1(self.b, "FRIDO_OP_STEP_ADD", sp, step=self.step.data_ptr(), delta=-1)
-                self.x.copy_(self.x_save)
-                p = tail(hist=(hist[0],))                   # row 0 carries ab = (1, 1) / 2
-                p.run(sp)
-            else:
-                k = min(i, 3)
-                older = tuple(hist[(i - j) % 4] for j in range(1, k + 1))
-                p = tail(eps_out=hist[i % 4], hist=older)
-                p.run(sp)
-            _run1(self.b, "FRIDO_OP_STEP_ADD", sp, step=self.step.data_ptr(), delta=1)
+            go(g_first if i == 0 else g_body)
             self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
 
 
@@ -300,20 +311,23 @@ class DecoderRuntime:
         self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
         self.plans = {}
 
-    def decode(self, z, inv_scale=None, return_code=False, to_uint8=False):
+    def decode(self, z, inv_scale=None, return_code=False, to_uint8=False, force_codes=None):
         """z (B, Ctot, h, w) NCHW latent -> image (B, 3, H, W); inv_scale: per-scale multiplier (1/scale_factor).
         to_uint8: return the (B, H, W, 3) uint8 array of scripts/sample_diffusion.py:115-121 instead (4x smaller to
         gather / write)."""
         B, Ct, h, w = z.shape
         embed = self.cfg["embed_dim"]
         inv = tuple(float(v) for v in (inv_scale if inv_scale is not None else [1.0] * len(embed)))
-        key = (B, h, w, inv)
+        key = (B, h, w, inv, force_codes is not None)
         st = current_stream_ptr(self.device)
         if key not in self.plans:
             z_state = torch.zeros(B, h * w, Ct, dtype=torch.float32, device=self.device)
             self.plans[key] = (z_state, VQDecodePlan(self.b, self.cfg["ddconfig"], embed, self.cfg["n_embed"], B=B, h=h, w=w,
-                                                      z_state=z_state, inv_scale=inv))
+                                                      z_state=z_state, inv_scale=inv, forced=force_codes is not None))
         z_state, plan = self.plans[key]
+        if force_codes is not None:      # test hook: decode the given per-scale code maps instead of the argmin's
+            for dst, src in zip(plan.force_idx, force_codes):
+                dst.copy_(torch.as_tensor(src, dtype=torch.int64).reshape(-1))
         zc = z.contiguous().float()
         _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=zc.data_ptr(), dst=z_state.data_ptr(), B=B, HW=h * w, Csrc=Ct, c0=0,
               Cuse=Ct, Cdst=Ct, d0=0, to_nchw=0)

@@ -1,13 +1,18 @@
 """DDIMSampler / PLMSSampler with the reference's constructor and `.sample(...)` signature
 (frido/models/diffusion/ddim.py:11-114, plms.py:11-114), driving the HIP SamplerEngine.
 
-Noise: the reference draws x_T and one torch.randn per update from torch's global generator.  With
-noise="torch" (default) the same draws are made on the host in the same order and uploaded, so a run
-after torch.manual_seed(s) consumes exactly the reference's noise stream; noise="philox" uses the
-device counter RNG keyed by (seed, global sample index) instead (no host involvement, shard-invariant).
+Noise: the reference draws x_T and one torch.randn per update from torch's global generator of the device it runs on.
+With noise="torch" (default) the same draws are made from the HOST generator in the same order and uploaded, so a run after
+torch.manual_seed(s) consumes exactly the noise stream of a reference run ON CPU with that seed (a reference run on a GPU
+draws from that device's generator, a different stream); noise="philox" uses the device counter RNG keyed by
+(seed, global sample index) instead (no host involvement, shard-invariant).
 """
+import collections
+
 import numpy as np
 import torch
+
+ENGINE_CACHE_SIZE = 4      # compiled SamplerEngines kept per denoiser (each owns per-stage plans, buffers and graphs)
 
 from . import schedules
 from ._lib import FridoHipError
@@ -41,14 +46,18 @@ class _SamplerBase:
         rt = unet.runtime()
         C, H, W = shape
         key = (self.KIND, B, C, H, W, nctx, S, float(eta), scale != 1.0, num_stage, float(temperature))
-        cache = rt.__dict__.setdefault("_sampler_engines", {})
-        if key not in cache:
+        cache = rt.__dict__.setdefault("_sampler_engines", collections.OrderedDict())
+        if key in cache:
+            cache.move_to_end(key)
+        else:
+            while len(cache) >= ENGINE_CACHE_SIZE:      # least-recently-used engine goes (frees its HBM)
+                cache.popitem(last=False)
             cache[key] = SamplerEngine(rt.b, unet.cfg, B=B, C=C, H=H, W=W, nctx=nctx, S=S, eta=eta, kind=self.KIND,
                                        alphas_cumprod=self.model.alphas_cumprod.detach().float().cpu().numpy(),
                                        embed_dim=self.model.embed_dim_list, cfg_scale=scale, num_stage=num_stage,
                                        temperature=temperature)
         eng = cache[key]
-        eng.cfg_scale = float(scale)
+        eng.cfg_scale = float(scale)      # read from a device scalar by the captured step bodies: one graph, any scale
         return eng
 
     @torch.no_grad()
@@ -62,8 +71,13 @@ class _SamplerBase:
                                       "(no shipped Frido sampling script uses them; quantize_x0 exit()s in the reference)")
         if conditioning is None or isinstance(conditioning, dict):
             raise NotImplementedError("cross-attention conditioning tensor required")
-        if conditioning.shape[0] != batch_size and verbose:
-            print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        if conditioning.shape[0] != batch_size:
+            # the reference only prints a warning here (ddim.py:87-93) and then fails (or silently broadcasts) inside the
+            # denoiser; a mismatched batch is never what the caller meant
+            raise ValueError(f"Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        if unconditional_conditioning is not None and unconditional_conditioning.shape != conditioning.shape:
+            raise ValueError(f"unconditional_conditioning {tuple(unconditional_conditioning.shape)} must match "
+                             f"conditioning {tuple(conditioning.shape)}")
         if not conditioning.is_cuda:
             raise FridoHipError("sample(): conditioning must live on the MI355X (there is no CPU path)")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)

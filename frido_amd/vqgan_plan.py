@@ -106,7 +106,7 @@ def decoder_body(b, B, dd, prefix, z_op, h, w, out):
 
 
 class VQDecodePlan:
-    def __init__(self, b: Builder, ddconfig, embed_dim, n_embed, *, B, h, w, z_state, inv_scale):
+    def __init__(self, b: Builder, ddconfig, embed_dim, n_embed, *, B, h, w, z_state, inv_scale, forced=False):
         """z_state: device f32 [B][h*w][sum(embed_dim)] NHWC latent (already in diffusion scale);
         inv_scale[i] multiplies scale i before quantisation."""
         self.b = b
@@ -120,13 +120,15 @@ class VQDecodePlan:
         self.out_nhwc = torch.zeros(B * self.H * self.W, a.out_ch, dtype=torch.float32, device=dev)
         self.idx = [torch.zeros(B * hw, dtype=torch.int64, device=dev) for _ in embed_dim]
         self.quant = torch.zeros(B * hw, Ct, dtype=torch.float32, device=dev)
+        self.force_idx = [torch.zeros(B * hw, dtype=torch.int64, device=dev) for _ in embed_dim] if forced else None
         prog = self.prog = b.new_prog()
         start = 0
         for i, e in enumerate(embed_dim):
             cb = b.dev_f32(f"ms_quantize.{i}.embedding.weight")
             prog.emit("FRIDO_OP_VQ", x=z_state.data_ptr(), npix=B * hw, Cx=Ct, c0=start, e=e, inv_scale=float(inv_scale[i]),
                       codebook=cb.data_ptr(), n_codes=n_embed[i], zq=self.quant.data_ptr(), Cq=Ct,
-                      q0=sum(embed_dim[i + 1:]), idx=self.idx[i].data_ptr())
+                      q0=sum(embed_dim[i + 1:]), idx=self.idx[i].data_ptr(),
+                      force_idx=self.force_idx[i].data_ptr() if forced else None)
             start += e
         q_op = b.pack(self.quant.data_ptr(), 1, B * hw, Ct, 0, Ct)
         pq = b.linear(q_op, "post_quant_conv", out="f32_strict")

@@ -191,6 +191,8 @@ typedef struct FridoVq {
     const float* codebook; int32_t n_codes;
     float* zq; int32_t Cq, q0;
     int64_t* idx;
+    const int64_t* force_idx;   /* test hook: use these code indices instead of the argmin (the decoder is then compared on
+                                   the reference's own codes, independent of VQ decision boundaries) */
 } FridoVq;
 
 /* One DDIM / PLMS state update (ddim.py:232-273, plms.py:247-303) on the NHWC f32 latent state
@@ -215,6 +217,14 @@ typedef struct FridoSamplerStep {
     float* x_out;                /* where x' goes (may alias x) */
     float* pred_x0;              /* optional [B][HW][Cx] */
     int32_t write_x;             /* 0: only eps_out/pred_x0 */
+    /* graph-replay forms (one captured step body serves every step / guidance scale):
+       cfg_dev: optional device float overriding cfg_scale;
+       hist_ring: PLMS eps history as a 4-slot ring [4][hist_stride] indexed by the DEVICE step counter instead of the
+       explicit hist1..3 / eps_out pointers.  hist_mode 1 (regular step, plms.py:175-177,285-301): the (CFG-mixed) eps of
+       step i goes to slot i & 3 and is combined with the min(i, 3) older slots (i-1) & 3, ...; hist_mode 3 (second half of
+       the Heun-style first step, plms.py:285-289): nothing is stored, eps is combined with slot i & 3. */
+    const float* cfg_dev;
+    float* hist_ring; int64_t hist_stride; int32_t hist_mode;
 } FridoSamplerStep;
 
 /* Stage hand-off (ddim.py:177-185): channels [c0,c1) of x[B][H][W][Cx] replaced by their
@@ -256,13 +266,17 @@ typedef struct FridoToU8 { const float* src; uint8_t* dst; int64_t n; } FridoToU
 /* step counter update: *step += delta (one thread). */
 typedef struct FridoStepAdd { int32_t* step; int32_t delta; } FridoStepAdd;
 
+/* device-to-device copy of n bytes (16-byte aligned, n % 16 == 0): a graph-capturable memcpy node for the sampler state
+ * save / restore of the PLMS first step (plms.py:285-289 evaluates eps at x_prev and then steps from x again). */
+typedef struct FridoCopy { const void* src; void* dst; int64_t n; } FridoCopy;
+
 /* fill a device buffer with a 32-bit pattern. */
 typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill;
 
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -272,7 +286,7 @@ typedef struct FridoOp {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small;
+        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small; FridoCopy copy;
         char _size[384];
     } u;
 } FridoOp;
@@ -298,6 +312,7 @@ int frido_place(const FridoPlace* d, frido_stream_t s);
 int frido_embed(const FridoEmbed* d, frido_stream_t s);
 int frido_to_u8(const FridoToU8* d, frido_stream_t s);
 int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s);
+int frido_copy(const FridoCopy* d, frido_stream_t s);
 /* One-launch GroupNorm (statistics + apply) on a FridoGnApply descriptor whose `partials` is unused; bf16 stream only.
  * frido_gn_fused_chunk returns the channel-chunk width it would use (and the workgroup size), or 0 if the descriptor does
  * not qualify -- then gn_stats + gn_apply is the path. */

@@ -88,14 +88,15 @@ def _handoff(img, s, num_stage, embed):
 
 @torch.no_grad()
 def ddim_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, eta=0.0, scale=1.0, uc=None,
-                noise=None, log_every_t=100, temperature=1.0):
-    """ddim.py:116-186.  apply_model(x, t, cond, stage) -> eps of that stage."""
+                noise=None, log_every_t=100, temperature=1.0, x_T=None):
+    """ddim.py:116-186.  apply_model(x, t, cond, stage) -> eps of that stage.  A supplied x_T is adopted as the finished
+    stage-0 result (ddim.py:150-152: stage 0 and its hand-off are skipped)."""
     noise = noise or NoiseSource()
     ts = ddim_timesteps(S)
     sig, al, alp = ddim_params(ac32, ts, eta)
     sq1m = np.sqrt(1.0 - al)
     b = shape[0]
-    img = noise(shape)
+    img = noise(shape) if x_T is None else x_T.clone()
     img_tmp = img.clone()
     inter = {"x_inter": [img], "pred_x0": [img]}
     total = ts.shape[0]
@@ -104,6 +105,8 @@ def ddim_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, eta
             img = img[:, :sum(splits[:1])]
         else:
             img = torch.cat((img, img_tmp[:, sum(splits[:s]):sum(splits[:s + 1])]), dim=1)
+        if x_T is not None and s == 0:
+            continue
         start = sum(embed[:s])
         for i, step in enumerate(np.flip(ts)):
             index = total - i - 1
@@ -121,14 +124,14 @@ def ddim_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, eta
 
 @torch.no_grad()
 def plms_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, scale=1.0, uc=None, noise=None,
-                log_every_t=100):
-    """plms.py:116-303 (eta must be 0, plms.py:25-26; noise is still drawn every update)."""
+                log_every_t=100, x_T=None):
+    """plms.py:116-303 (eta must be 0, plms.py:25-26; noise is still drawn every update; x_T: plms.py:150-152)."""
     noise = noise or NoiseSource()
     ts = ddim_timesteps(S)
     sig, al, alp = ddim_params(ac32, ts, 0.0)
     sq1m = np.sqrt(1.0 - al)
     b = shape[0]
-    img = noise(shape)
+    img = noise(shape) if x_T is None else x_T.clone()
     img_tmp = img.clone()
     inter = {"x_inter": [img], "pred_x0": [img]}
     total = ts.shape[0]
@@ -138,6 +141,8 @@ def plms_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, sca
             img = img[:, :sum(splits[:1])]
         else:
             img = torch.cat((img, img_tmp[:, sum(splits[:s]):sum(splits[:s + 1])]), dim=1)
+        if x_T is not None and s == 0:
+            continue
         start = sum(embed[:s])
         old = []
         for i, step in enumerate(time_range):

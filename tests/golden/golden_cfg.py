@@ -6,7 +6,8 @@ parity checks finish in seconds.  *_SMALL3 is the 3-scale variant of BASELINE co
 """
 import copy
 
-from frido_amd.configs import UNET_F8F4 as UNET_FULL, VQ_F8F4 as VQ_FULL, BERT_FULL, frido_cfg  # noqa: E402,F401
+from frido_amd.configs import (UNET_F8F4 as UNET_FULL, VQ_F8F4 as VQ_FULL, BERT_FULL, frido_cfg,  # noqa: E402,F401
+                               UNET_F16F8, VQ_F16F8, UNET_512, VQ_512)
 
 UNET_SMALL = dict(
     use_split_head=True, split_embed_dim_list=[3, 3], use_SPADE_norm=True, image_size=16,

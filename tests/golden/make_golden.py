@@ -34,7 +34,7 @@ _spec.loader.exec_module(H)
 
 sys.path.insert(0, HERE)
 from golden_cfg import (UNET_SMALL, UNET_FULL, VQ_SMALL, VQ_FULL, UNET_SMALL3, VQ_SMALL3, BERT_SMALL,  # noqa: E402
-                        frido_cfg)
+                        frido_cfg, BERT_FULL, UNET_F16F8, VQ_F16F8, UNET_512, VQ_512)
 
 
 def fill_module(mod, prefix=""):
@@ -251,6 +251,164 @@ def gen_sampler(tag, ucfg, vcfg, bcfg, B, nctx):
     save(tag, **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# Full-size end-to-end fixtures (BASELINE.json configs 1, 3, 5).  The per-step noise is NOT stored (it would be MBs of
+# incompressible floats): the runs draw from torch's CPU generator after torch.manual_seed(23), which the HIP samplers'
+# noise="torch" mode reproduces draw for draw; a checksum of the stream is stored so that a generator mismatch is
+# reported as such.
+def _decode_with_codes(model, samples):
+    """decode_first_stage (frido.py:823-891) + the per-scale codes (the reference drops return_code for VQ first stages)."""
+    z = samples.clone()
+    start = 0
+    for i, e in enumerate(model.first_stage_model.embed_dim):
+        z[:, start:start + e] *= 1. / model.scale_factor[i]
+        start += e
+    dec, code = model.first_stage_model.decode(z, return_code=True)
+    return dec, np.asarray(code, dtype=np.int64)
+
+
+def _pack_img(out, name, img, ss):
+    out[f"{name}_img"] = img.numpy()[:, :, ::ss, ::ss]
+    out[f"{name}_img_sum"] = np.float64(img.double().sum().item())
+    out[f"{name}_img_abs_sum"] = np.float64(img.double().abs().sum().item())
+    out[f"{name}_img_ss"] = np.int64(ss)
+
+
+def _run_sampler(out, model, name, sampler_cls, S, eta, scale, c, uc, shape, nstage, log_every_t, ss, x_T=None):
+    torch.manual_seed(23)
+    smp = sampler_cls(model)
+    with NoiseTape() as tape, torch.no_grad():
+        samples, inter = smp.sample(S=S, batch_size=c.shape[0], shape=shape, conditioning=c, num_stage=nstage, eta=eta,
+                                    verbose=False, log_every_t=log_every_t, unconditional_guidance_scale=scale,
+                                    unconditional_conditioning=uc if scale != 1.0 else None, x_T=x_T)
+        img = model.decode_first_stage(samples)
+        img2, code = _decode_with_codes(model, samples)
+    assert torch.equal(img, img2)
+    flat = np.concatenate([d.reshape(-1) for d in tape.draws]) if tape.draws else np.zeros(0, np.float32)
+    out[f"{name}_samples"] = samples.numpy()
+    out[f"{name}_code"] = code.astype(np.int32)
+    _pack_img(out, name, img, ss)
+    out[f"{name}_noise_n"] = np.int64(flat.size)
+    out[f"{name}_noise_sum"] = np.float64(flat.astype(np.float64).sum())
+    out[f"{name}_noise_head"] = flat[:16].copy()
+    out[f"{name}_nx"] = np.int64(len(inter["x_inter"]))
+    out[f"{name}_x_inter_last"] = inter["x_inter"][-1].numpy()
+    out[f"{name}_pred_x0_1"] = inter["pred_x0"][1].numpy() if len(inter["pred_x0"]) > 1 else np.zeros(0, np.float32)
+    out[f"{name}_args"] = np.array([S, eta, scale, log_every_t], dtype=np.float64)
+    return samples
+
+
+def gen_sampler_full():
+    """BASELINE config 1: layout2i f8f4 at full width, B = 1, DDIM-50 eta = 1 (ddim.py:116-186, frido.py:823-891), plus
+    DDIM-4; context = the real 32-layer cond stage on random layout tokens."""
+    DDIM, PLMS = H.patch_samplers()
+    bcfg = dict(BERT_FULL, vocab_size=1024 + 256)
+    model = build_frido(UNET_FULL, VQ_FULL, bcfg)
+    B, nctx = 1, 26
+    tokens = torch.from_numpy(np.random.default_rng(11).integers(0, 1024, (B, nctx)))
+    with torch.no_grad():
+        c = model.get_learned_conditioning(tokens)
+    out = {"tokens": tokens.numpy(), "c": c.numpy(), "scale_factor": model.scale_factor.numpy()}
+    _run_sampler(out, model, "ddim4", DDIM, 4, 1.0, 1.0, c, None, (6, 64, 64), 2, 2, 4)
+    _run_sampler(out, model, "ddim50", DDIM, 50, 1.0, 1.0, c, None, (6, 64, 64), 2, 10, 4)
+    save("sampler_full", **out)
+
+
+class _Ident(torch.nn.Module):
+    def forward(self, x):
+        return x
+
+
+def _frido_no_cond(ucfg, vcfg, nscale):
+    fr = H.import_ref("frido.models.diffusion.frido")
+    H.patch_samplers()
+    cfg = frido_cfg(ucfg, vcfg, dict())
+    cfg["first_stage_config"]["params"]["lossconfig"] = {"target": "torch.nn.Identity"}
+    cfg["cond_stage_config"] = {"target": "torch.nn.Identity"}      # conditioning tensors are fed directly
+    cfg["cond_stage_trainable"] = False
+    model = fr.FridoDiffusion(**cfg)
+    fill_module(model.model, "model.")
+    fill_module(model.first_stage_model, "first_stage_model.")
+    model.scale_factor.copy_(torch.tensor([0.9, 1.1, 1.05][:nscale]))
+    return model.eval()
+
+
+def gen_sampler_t2i():
+    """BASELINE config 3 at its true dimensions (configs/frido/t2i/frido_f16f8_coco_clip.yaml:21-77): latent 8 x 32 x 32,
+    split [4, 4], context = ONE L2-normalised 768-d token (encoders/modules.py:210-219), PLMS (plms.py:116-194) with
+    classifier-free guidance 1.5 (tools/frido/eval_t2i_clip.sh), f16f8 first stage with 2 x 8192 codes."""
+    DDIM, PLMS = H.patch_samplers()
+    model = _frido_no_cond(UNET_F16F8, VQ_F16F8, 2)
+    B = 2
+    c = T(seeded_normal("t2i_full:c", (B, 1, 768)))
+    c = c / torch.linalg.norm(c, dim=2, keepdim=True)
+    uc = T(seeded_normal("t2i_full:uc", (1, 1, 768)))
+    uc = (uc / torch.linalg.norm(uc, dim=2, keepdim=True)).repeat(B, 1, 1)
+    out = {"c": c.numpy(), "uc": uc.numpy(), "scale_factor": model.scale_factor.numpy()}
+    _run_sampler(out, model, "plms_cfg", PLMS, 6, 0.0, 1.5, c, uc, (8, 32, 32), 2, 2, 4)
+    _run_sampler(out, model, "ddim_cfg", DDIM, 4, 0.0, 1.5, c, uc, (8, 32, 32), 2, 2, 4)
+    # one denoiser forward per stage (pyunet.py:867-950) for a tight single-forward bound
+    net = model.model.diffusion_model
+    x = T(seeded_normal("t2i_full:x", (B, 8, 32, 32)))
+    out["x"] = x.numpy()
+    for s in range(2):
+        t = torch.tensor([996 - 37 * i for i in range(B)], dtype=torch.long)
+        with torch.no_grad():
+            e = net(x[:, :4 * (s + 1)].contiguous(), t, context=c, stage=s)
+        out[f"t_{s}"], out[f"eps_{s}"] = t.numpy(), e.numpy()
+    save("sampler_t2i", **out)
+
+
+def gen_unet_512():
+    """BASELINE config 5 denoiser: 3 stages on a 9 x 128 x 128 latent, 92 context tokens; one forward per stage."""
+    net = build_unet(UNET_512)
+    B, nctx, hw = 1, 92, 128
+    x = T(seeded_normal("u512:x", (B, 9, hw, hw)))
+    ctx = T(seeded_normal("u512:ctx", (B, nctx, 640)))
+    out = {"x": x.numpy(), "ctx": ctx.numpy()}
+    for s in range(3):
+        t = torch.tensor([801 - 250 * s], dtype=torch.long)
+        with torch.no_grad():
+            e = net(x[:, :3 * (s + 1)].contiguous(), t, context=ctx, stage=s)
+        out[f"t_{s}"], out[f"eps_{s}"] = t.numpy(), e.numpy()
+        print("stage", s, "done", float(e.abs().max()))
+    save("unet_512", **out)
+
+
+def gen_vq_512():
+    """BASELINE config 5 first stage: decode of a 9 x 128 x 128 latent to 512 x 512 (AttnBlock over 16384 keys,
+    taming/modules/diffusionmodules/model.py:168-192)."""
+    net = build_vq(VQ_512)
+    h = T(seeded_normal("vq512:h", (1, 9, 128, 128)) * 1.5)
+    with torch.no_grad():
+        dec, code = net.decode(h, return_code=True)
+    out = {"h": h.numpy(), "code": np.asarray(code, dtype=np.int32)}
+    _pack_img(out, "dec", dec, 8)
+    save("vq_512", **out)
+
+
+def gen_sampler_xt():
+    """The x_T quirk (ddim.py:150-152, plms.py:150-152): a supplied x_T is taken as the FINISHED stage-0 result -- stage 0
+    and its pooling hand-off are skipped."""
+    DDIM, PLMS = H.patch_samplers()
+    model = build_frido(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    g = np.load(os.path.join(HERE, "sampler_small.npz"))
+    c = T(g["c"])
+    out = {}
+    xT = T(seeded_normal("xt:x", (2, 6, 16, 16)))
+    out["x_T"] = xT.numpy()
+    for name, cls, S, eta in (("ddim", DDIM, 4, 1.0), ("plms", PLMS, 4, 0.0)):
+        torch.manual_seed(23)
+        with NoiseTape() as tape, torch.no_grad():
+            samples, inter = cls(model).sample(S=S, batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=eta,
+                                               verbose=False, log_every_t=2, x_T=xT)
+        out[f"{name}_samples"] = samples.numpy()
+        out[f"{name}_noise"] = np.concatenate([d.reshape(-1) for d in tape.draws])
+        out[f"{name}_nx"] = np.int64(len(inter["x_inter"]))
+    # single-stage model: x_T comes back unchanged
+    save("sampler_xt", **out)
+
+
 GENS = {
     "schedules": gen_schedules,
     "unet_small": lambda: gen_unet("unet_small", UNET_SMALL, B=2, nctx=5, hw=16),
@@ -260,6 +418,11 @@ GENS = {
     "vq_full": lambda: gen_vq("vq_full", VQ_FULL, B=1, subsample=8),
     "sampler_small": lambda: gen_sampler("sampler_small", UNET_SMALL, VQ_SMALL, BERT_SMALL, B=2, nctx=5),
     "sampler_small3": lambda: gen_sampler("sampler_small3", UNET_SMALL3, VQ_SMALL3, BERT_SMALL, B=1, nctx=7),
+    "sampler_xt": gen_sampler_xt,
+    "sampler_full": gen_sampler_full,
+    "sampler_t2i": gen_sampler_t2i,
+    "unet_512": gen_unet_512,
+    "vq_512": gen_vq_512,
 }
 
 if __name__ == "__main__":

@@ -144,3 +144,63 @@ def test_checkpoint_ingestion_roundtrip(tmp_path):
         assert float(dst.model.diffusion_model.time_embed[0].weight.mean()) == 0.5
     assert torch.equal(dst.model.diffusion_model.time_embed[0].weight, w0)    # ... and restored
     assert torch.equal(dst.scale_factor, torch.tensor([0.7, 1.3]))
+
+
+def test_sampling_script_import_surface():
+    """Every name scripts/sample_diffusion.py:16-21 imports from the model packages resolves here (the CLI's DataModule /
+    PNG writer are host I/O and stay the reference's own)."""
+    from frido.util import log_txt_as_img, exists, default, ismap, isimage, mean_flat, count_params  # noqa: F401
+    from frido.util import instantiate_from_config_main as instantiate_from_config  # noqa: F401
+    from frido.models.diffusion.ddim import DDIMSampler  # noqa: F401
+    from frido.models.diffusion.plms import PLMSSampler  # noqa: F401
+    from taming.data.utils import custom_collate
+    assert exists(0) and not exists(None) and default(None, lambda: 3) == 3 and default(2, 5) == 2
+    assert ismap(torch.zeros(1, 4, 2, 2)) and not ismap(torch.zeros(1, 3, 2, 2)) and isimage(torch.zeros(1, 3, 2, 2))
+    assert not isimage(np.zeros((1, 3, 2, 2))) and mean_flat(torch.ones(2, 3, 4)).tolist() == [1.0, 1.0]
+    assert count_params(torch.nn.Linear(3, 2)) == 8
+    img = log_txt_as_img((64, 32), ["a caption", ["x", "y"]], size=8)
+    assert img.shape == (2, 3, 32, 64) and float(img.max()) <= 1.0 and float(img.min()) >= -1.0
+    # collate: tensors stack, strings stay lists, dicts recurse, ragged per-sample Annotation lists pass through
+    import collections
+    Annotation = collections.namedtuple("Annotation", "bbox category_no")
+    batch = [{"image": torch.zeros(4, 4, 3), "objects_bbox": torch.arange(26), "file_name": "a.png",
+              "annotations": [Annotation((0, 0, 1, 1), 3)]},
+             {"image": torch.ones(4, 4, 3), "objects_bbox": torch.arange(26) + 1, "file_name": "b.png",
+              "annotations": [Annotation((0, 0, 1, 1), 5), Annotation((0, 0, .5, .5), 7)]}]
+    out = custom_collate(batch)
+    assert out["image"].shape == (2, 4, 4, 3) and out["objects_bbox"].shape == (2, 26) and out["file_name"] == ["a.png", "b.png"]
+    assert len(out["annotations"]) == 2 and len(out["annotations"][1]) == 2
+    assert custom_collate([1, 2]).tolist() == [1, 2] and custom_collate([np.ones(3), np.zeros(3)]).shape == (2, 3)
+
+
+def test_caller_surface_of_frido_diffusion():
+    """get_img_ids (frido.py:818), q_sample (frido.py:302-320), the CLIP cond-stage target of the t2i YAML."""
+    from frido_amd.models import instantiate_from_config
+    from frido_amd import schedules as sch
+    cfg = frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    cfg["cond_stage_config"] = dict(target="frido.modules.encoders.modules.FrozenCLIPTextEmbedder")
+    cfg["cond_stage_trainable"], cfg["cond_stage_key"] = False, "caption"
+    m = instantiate_from_config(dict(target="ldm.models.diffusion.msldm.MSLatentDiffusion", params=cfg))
+    assert m.cond_stage_model.use_tknz_fn and m.get_img_ids({"file_name": ["x"]}) == ["x"]
+    with pytest.raises(NotImplementedError, match="not reachable"):
+        m.get_learned_conditioning(["a photo"])
+    x0 = torch.randn(2, 6, 4, 4)
+    t = torch.tensor([10, 900])
+    nz = torch.randn_like(x0)
+    a, s1 = m.sqrt_alphas_cumprod[t].view(2, 1, 1, 1), m.sqrt_one_minus_alphas_cumprod[t].view(2, 1, 1, 1)
+    assert torch.equal(m.q_sample(x0, t, noise=nz), a * x0 + s1 * nz)
+    q = m.q_sample(x0, t, ch_start=3, ch_end=5, noise=nz, mix_tau=0.25)
+    assert torch.equal(q[:, 5:], nz[:, 5:]) and torch.equal(q[:, 3:5], (a * x0 + s1 * nz)[:, 3:5])
+    assert torch.allclose(q[:, :3], 0.75 * x0[:, :3] + 0.25 * nz[:, :3])
+
+
+def test_sampler_argument_validation_on_cpu():
+    from frido_amd.samplers import DDIMSampler, PLMSSampler
+
+    class M:
+        num_timesteps = 1000
+        alphas_cumprod = torch.from_numpy(schedules.ddpm_tables(schedules.make_beta_schedule("linear", 1000, linear_start=0.0015, linear_end=0.0155))["alphas_cumprod"])
+    with pytest.raises(ValueError, match="conditionings"):
+        DDIMSampler(M()).sample(S=4, batch_size=2, shape=(6, 16, 16), conditioning=torch.zeros(1, 5, 64), verbose=False)
+    with pytest.raises(ValueError):
+        PLMSSampler(M()).make_schedule(ddim_num_steps=4, ddim_eta=0.5)

@@ -121,3 +121,96 @@ def test_bert_oracle_bit_exact():
         g = golden(name)
         c = bert_embed(sd, torch.from_numpy(g["tokens"]), BERT_SMALL["n_layer"])
         assert torch.equal(c, torch.from_numpy(g["c"]))
+
+
+def test_sampler_oracle_x_T_quirk():
+    """ddim.py:150-152 / plms.py:150-152: x_T is adopted as the finished stage-0 result."""
+    g = golden("sampler_xt")
+    c = torch.from_numpy(golden("sampler_small")["c"])
+    usd = synth_sd(unet_holder(UNET_SMALL), "model.diffusion_model.")
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    am = lambda x, t, cond, s: unet_forward(usd, UNET_SMALL, x, t, cond, s)
+    xT = torch.from_numpy(g["x_T"])
+    out, inter = S.ddim_sample(am, ac, 4, (2, 6, 16, 16), c, [3, 3], [3, 3], 2, eta=1.0, noise=S.NoiseSource(g["ddim_noise"]),
+                               log_every_t=2, x_T=xT)
+    assert torch.equal(out, torch.from_numpy(g["ddim_samples"])) and len(inter["x_inter"]) == int(g["ddim_nx"])
+    assert torch.equal(out[:, :3], xT[:, :3])            # stage-0 channels pass through un-denoised and un-pooled
+    out, inter = S.plms_sample(am, ac, 4, (2, 6, 16, 16), c, [3, 3], [3, 3], 2, noise=S.NoiseSource(g["plms_noise"]),
+                               log_every_t=2, x_T=xT)
+    assert torch.equal(out, torch.from_numpy(g["plms_samples"])) and len(inter["x_inter"]) == int(g["plms_nx"])
+    one, _ = S.ddim_sample(am, ac, 4, (2, 3, 16, 16), c, [3], [3], 1, eta=1.0, x_T=xT[:, :3])
+    assert torch.equal(one, xT[:, :3])                   # single stage: x_T comes back unchanged
+
+
+def _check_img(img, g, name, tol):
+    ss = int(g[f"{name}_img_ss"])
+    ref = torch.from_numpy(g[f"{name}_img"])
+    assert float((img[:, :, ::ss, ::ss] - ref).abs().max()) < tol
+    assert abs(float(img.double().sum()) - float(g[f"{name}_img_sum"])) < 1e-5 * float(g[f"{name}_img_abs_sum"])
+
+
+@pytest.mark.slow
+def test_t2i_true_dims_oracle():
+    """BASELINE config 3 at the reference's real f16f8 dimensions: PLMS + CFG 1.5, one 768-d context token."""
+    from golden_cfg import UNET_F16F8, VQ_F16F8
+    g = golden("sampler_t2i")
+    usd = synth_sd(unet_holder(UNET_F16F8), "model.diffusion_model.")
+    vsd = synth_sd(vq_holder(VQ_F16F8), "first_stage_model.")
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    c, uc = torch.from_numpy(g["c"]), torch.from_numpy(g["uc"])
+    am = lambda x, t, cond, s: unet_forward(usd, UNET_F16F8, x, t, cond, s)
+    x = torch.from_numpy(g["x"])
+    for s in range(2):
+        e = am(x[:, :4 * (s + 1)], torch.from_numpy(g[f"t_{s}"]), c, s)
+        assert float((e - torch.from_numpy(g[f"eps_{s}"])).abs().max()) < 1e-5
+    Sx, eta, scale, lev = g["plms_cfg_args"]
+    torch.manual_seed(23)
+    ns = S.NoiseSource()
+    out, inter = S.plms_sample(am, ac, int(Sx), (2, 8, 32, 32), c, [4, 4], [4, 4], 2, scale=float(scale), uc=uc, noise=ns,
+                               log_every_t=int(lev))
+    assert float((out - torch.from_numpy(g["plms_cfg_samples"])).abs().max()) < 2e-5
+    assert len(inter["x_inter"]) == int(g["plms_cfg_nx"])
+    img, codes = vq_decode(vsd, VQ_F16F8, S.decode_first_stage(lambda z: z, out, g["scale_factor"].tolist(), [4, 4]), return_code=True)
+    assert np.mean(np.stack([cd.numpy() for cd in codes]).reshape(-1) != g["plms_cfg_code"].reshape(-1)) < 1e-3
+    # decode on the reference's own latent: the VQ decisions then agree and the pixels are comparable everywhere
+    img = S.decode_first_stage(lambda z: vq_decode(vsd, VQ_F16F8, z), torch.from_numpy(g["plms_cfg_samples"]), g["scale_factor"].tolist(), [4, 4])
+    _check_img(img, g, "plms_cfg", 2e-5)
+
+
+@pytest.mark.slow
+def test_512_three_scale_oracle():
+    """BASELINE config 5: denoiser on the 9 x 128 x 128 latent (stage 2: two SPADE-conditioned pyramids), and the 512 x 512
+    decode with 16384-key attention blocks."""
+    from golden_cfg import UNET_512, VQ_512
+    g = golden("unet_512")
+    usd = synth_sd(unet_holder(UNET_512), "model.diffusion_model.")
+    x, ctx = torch.from_numpy(g["x"]), torch.from_numpy(g["ctx"])
+    e = unet_forward(usd, UNET_512, x, torch.from_numpy(g["t_2"]), ctx, 2)
+    assert float((e - torch.from_numpy(g["eps_2"])).abs().max()) < 2e-5
+    del usd
+    gv = golden("vq_512")
+    vsd = synth_sd(vq_holder(VQ_512), "first_stage_model.")
+    dec, codes = vq_decode(vsd, VQ_512, torch.from_numpy(gv["h"]), return_code=True)
+    assert np.array_equal(np.stack([cd.numpy() for cd in codes]).reshape(gv["code"].shape), gv["code"])
+    _check_img(dec, gv, "dec", 2e-5)
+
+
+@pytest.mark.slow
+def test_full_width_ddim4_oracle():
+    """BASELINE config 1 plumbing at DDIM-4: the real 32-layer cond stage, both stages at full width, decode."""
+    from golden_cfg import BERT_FULL
+    from frido_amd.models import BERTEmbedder
+    from oracle.bert import bert_embed
+    g = golden("sampler_full")
+    bcfg = dict(BERT_FULL, vocab_size=1024 + 256)
+    c = bert_embed(synth_sd(BERTEmbedder(**bcfg), "cond_stage_model."), torch.from_numpy(g["tokens"]), bcfg["n_layer"])
+    assert float((c - torch.from_numpy(g["c"])).abs().max()) < 1e-5
+    usd = synth_sd(unet_holder(UNET_FULL), "model.diffusion_model.")
+    vsd = synth_sd(vq_holder(VQ_FULL), "first_stage_model.")
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    am = lambda x, t, cond, s: unet_forward(usd, UNET_FULL, x, t, cond, s)
+    torch.manual_seed(23)
+    out, inter = S.ddim_sample(am, ac, 4, (1, 6, 64, 64), torch.from_numpy(g["c"]), [3, 3], [3, 3], 2, eta=1.0, log_every_t=2)
+    assert float((out - torch.from_numpy(g["ddim4_samples"])).abs().max()) < 2e-5
+    img = S.decode_first_stage(lambda z: vq_decode(vsd, VQ_FULL, z), torch.from_numpy(g["ddim4_samples"]), g["scale_factor"].tolist(), [3, 3])
+    _check_img(img, g, "ddim4", 2e-5)
