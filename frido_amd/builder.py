@@ -14,6 +14,7 @@ ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample convs as four 2x2 phase convolutions
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
+ATTN_FLASH = os.environ.get("FRIDO_ATTN_FLASH", "1") != "0"       # flash-style kernel for long key sequences (flash.hip)
 
 
 class Builder:
@@ -391,21 +392,33 @@ class Builder:
         [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158).
         stream=True (the out projection is folded into vT): returns the residual-stream activation O + bias + residual."""
         Np = rup(Nk, 32)
+        aligned = ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0
+        small = Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and aligned
+        flash = (not small and ATTN_FLASH and aligned and _lib.lib().frido_attn_flash_supported(d))
+        if small or flash:
+            # one launch, scores stay on chip: the short-key kernel (cross-attention, 8x8 planes) or the flash-style kernel
+            kind = "FRIDO_OP_ATTN_SMALL" if small else "FRIDO_OP_ATTN_FLASH"
+            kw = dict(Q=q.ptr + 2 * q_off, q_lo=q.lo, ldq=ldq, K=k.ptr + 2 * k_off, k_lo=k.lo, k_bs=Nk * ldk, ldk=ldk, VT=vT.ptr,
+                      vt_lo=vT.lo, vt_bs=d * Np, ldvt=Np, B=B, Nq=Nq, Nk=Nk, d=d, dv=d, nsplit=self.nsplit, alpha=float(d) ** -0.5)
+            if stream:
+                res = self.f32(B * Nq, d)
+                assert residual is None or getattr(residual, "bf16", False) == res.bf16
+                self.prog.emit(kind, out_act=res.ptr, ld_act=d, residual=residual.ptr if residual is not None else None,
+                               ldr=residual.C if residual is not None else 0, bias=bias_ptr, act_bf16=int(res.bf16), **kw)
+                return res
+            o = self.op(B * Nq, d)
+            self.prog.emit(kind, out_op=o.ptr, out_lo=o.lo, ldo=d, **kw)
+            return o
+        if Nk > 4096:
+            raise _lib.FridoHipError(f"attention over {Nk} keys with head dim {d}: the flash kernel is instantiated for "
+                                     "d in {128, 256, 384, 512, 576} only and the score-matrix path stops at 4096 keys")
+        s = self.f32_strict(B * Nq, Nk)
+        self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
+                       a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)
+        p = self.softmax(s, B * Nq, Nk, Nk, Np)
+        s.free()
         if stream:
             res = self.f32(B * Nq, d)
-            if Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0:
-                self.prog.emit("FRIDO_OP_ATTN_SMALL", Q=q.ptr + 2 * q_off, q_lo=q.lo, ldq=ldq, K=k.ptr + 2 * k_off, k_lo=k.lo,
-                               k_bs=Nk * ldk, ldk=ldk, VT=vT.ptr, vt_lo=vT.lo, vt_bs=d * Np, ldvt=Np, out_act=res.ptr, ld_act=d,
-                               residual=residual.ptr if residual is not None else None, ldr=residual.C if residual is not None else 0,
-                               bias=bias_ptr, act_bf16=int(res.bf16), B=B, Nq=Nq, Nk=Nk, d=d, dv=d, nsplit=self.nsplit,
-                               alpha=float(d) ** -0.5)
-                assert residual is None or getattr(residual, "bf16", False) == res.bf16
-                return res
-            s = self.f32_strict(B * Nq, Nk)
-            self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
-                           a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)
-            p = self.softmax(s, B * Nq, Nk, Nk, Np)
-            s.free()
             kw = {}
             if residual is not None:
                 kw.update(residual=residual.ptr, ldr=residual.C, res_bs=Nq * residual.C, res_bf16=getattr(residual, "bf16", False))
@@ -413,18 +426,6 @@ class Builder:
                            of_bs=Nq * d, ldo=d, out_bf16=res.bf16, **kw)
             p.free()
             return res
-        if Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0:
-            # short key sequence: one fused launch, scores stay on chip
-            o = self.op(B * Nq, d)
-            self.prog.emit("FRIDO_OP_ATTN_SMALL", Q=q.ptr + 2 * q_off, q_lo=q.lo, ldq=ldq, K=k.ptr + 2 * k_off, k_lo=k.lo,
-                           k_bs=Nk * ldk, ldk=ldk, VT=vT.ptr, vt_lo=vT.lo, vt_bs=d * Np, ldvt=Np, out_op=o.ptr, out_lo=o.lo,
-                           ldo=d, B=B, Nq=Nq, Nk=Nk, d=d, dv=d, nsplit=self.nsplit, alpha=float(d) ** -0.5)
-            return o
-        s = self.f32_strict(B * Nq, Nk)
-        self.prog.gemm(Nq, Nk, d, (q.ptr + 2 * q_off, q.lo), (k.ptr + 2 * k_off, k.lo), batch=B, lda=ldq, ldb=ldk,
-                       a_bs=Nq * ldq, b_bs=Nk * ldk, alpha=float(d) ** -0.5, out_f32=s.ptr, of_bs=Nq * Nk, ldo=Nk)
-        p = self.softmax(s, B * Nq, Nk, Nk, Np)
-        s.free()
         o = self.op(B * Nq, d)
         self.prog.gemm(Nq, d, Np, p, vT, batch=B, lda=Np, ldb=Np, a_bs=Nq * Np, b_bs=d * Np, out_op=o.ptr,
                        oo_bs=Nq * d, ldoo=d, oo_lo=o.lo)

@@ -1,0 +1,360 @@
+// Flash-style single-head attention for LONG key sequences (gfx950): O = softmax(alpha * Q K^T) V without ever forming the
+// [Nq][Nk] score matrix -- online softmax over 32-key tiles.  Covers the self-attention of the U-Net's large planes
+// (frido/modules/attention.py:170-193: 1024 / 4096 tokens, d = C = 384 / 576) and the VQGAN AttnBlocks
+// (taming/modules/diffusionmodules/model.py:168-192: 4096 tokens at 256^2, 16384 at 512^2, d = 128 .. 512), which the
+// three-kernel path (QK^T GEMM -> f32 scores -> row softmax -> PV GEMM) served before: 1 GiB of scores per image at
+// 16384 keys.  The heads here are SINGLE heads with d = C up to 576, so the tiling is over d, not over heads.
+//
+// Everything is computed TRANSPOSED so that one query lives in one MFMA column (= lane & 15) through the whole kernel:
+//     S^T[key][q] = K_tile . Q^T      A = K fragment (LDS), B = Q fragment (registers, loaded once)
+//     O^T[c][q]  += V^T_tile . P^T    A = V^T fragment (LDS), B = P fragment (registers)
+//   * v_mfma_f32_16x16x32_bf16 leaves lane l with D[row = 4 (l>>4) + e][col = l & 15]: every lane's S values belong to ONE
+//     query, so the row max / row sum are 8 in-register ops + two cross-lane steps (xor 16, 32), and the running
+//     (max, sum, rescale factor) of a query sit in the lane that owns its O^T column: no broadcast, no LDS round trip;
+//   * the K rows of a 32-key tile are stored PERMUTED in LDS (key 8a + 4t + b at row 16t + 4a + b; the permutation rides
+//     on the per-lane SOURCE address of the LDS-DMA) so that the two S^T fragments of a lane hold keys 8g .. 8g+7 -- exactly
+//     the 8 k-slots of the B operand of the PV MFMA: P goes from accumulator registers to operand registers by a pack;
+//   * workgroup = NW waves x 16 queries.  Two 2-stage phases per key tile, each covered by the other's DMA:
+//       phase 1: wait K_j, barrier, issue V^T_j, S^T = K_j Q^T, online softmax, rescale O^T
+//       phase 2: wait V^T_j, barrier, issue K_{j+1}, O^T += V^T_j P^T
+//     K / V^T tiles go L2 -> LDS by global_load_lds_dwordx4 in the [rows][64 B] sub-tile layout of igemm.hip (XOR slot
+//     swizzle on the source address, conflict-free ds_read_b128 fragments); fragment reads are inline asm so that hipcc does
+//     not drain the DMA queue in front of them;
+//   * bf16x3 mode (NS = 2): Q, K, V^T and P carry hi + lo bf16 planes, products are hi*hi + hi*lo + lo*hi in f32.
+#include "common.h"
+#include <atomic>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS>
+__device__ __forceinline__ f32x4 mma3(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x4 acc) {
+    if constexpr (NS == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float xor_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// OS > 1: the O^T rows (output channels) are split over gridDim.y workgroups, each recomputing S^T (bit-identically) -- used
+// where hi + lo planes of Q plus all D / 16 accumulator fragments do not fit the register file (bf16x3 mode, d >= 512).
+template <int D, int NS, int NW, int OS>
+struct FGeo {
+    static constexpr int BKV = 32;                       // keys per tile
+    static constexpr int KS = D / 32, CT = D / 16 / OS;  // QK^T k-steps; O^T row fragments of this workgroup
+    static constexpr int KPL = BKV * D * 2;              // bytes of one K plane of a tile  ([KS][32 rows][64 B])
+    static constexpr int VPL = D / OS * BKV * 2;         // bytes of one V^T plane of a tile ([D / OS rows][64 B])
+    static constexpr int KBUF = NS * KPL, VBUF = NS * VPL;
+    static constexpr int SMEM = KBUF + VBUF;
+    static constexpr int KP = KS * 2, VP = D / 16 / OS;  // 1-KiB DMA pieces per plane
+    static_assert(D % (32 * OS) == 0 && SMEM <= 163840, "LDS budget");
+    static_assert(NW % 2 == 0, "a wave's K pieces all belong to one 16-row half");
+};
+
+// FridoAttnSmall descriptor (include/frido_hip.h); requirements checked by the launcher.
+template <int D, int NS, int NW, int OS>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(const FridoAttnSmall d) {
+    using G = FGeo<D, NS, NW, OS>;
+    constexpr int KS = G::KS, CT = G::CT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int BQ = NW * 16;
+
+    // workgroup -> (sample, query block); consecutive logical ids (one sample's blocks share K / V) land on one XCD's L2
+    const int qblocks = (d.Nq + BQ - 1) / BQ;
+    const int nb = qblocks * d.B;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    }
+    const int z = bid / qblocks, qb = bid - z * qblocks;
+    const int q0 = qb * BQ + wave * 16;                  // first query of this wave (within the sample)
+    int qrow = q0 + r;
+    const bool q_ok = qrow < d.Nq;
+    qrow = q_ok ? qrow : d.Nq - 1;
+    const int64_t grow = (int64_t)z * d.Nq + qrow;       // global row of Q / output
+
+    // ---- Q fragments: lane holds Q[q = r][32 ks + 8 g .. +8] for every k-step (B operand of S^T = K Q^T) ----
+    bf16x8 qf[KS][NS];
+    {
+        const frido_bf16* qp = d.Q + grow * d.ldq + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks][0] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+            if constexpr (NS == 2) qf[ks][1] = *reinterpret_cast<const bf16x8*>(qp + d.q_lo + ks * 32);
+        }
+    }
+
+    // ---- DMA source offsets.  A 1-KiB piece = 16 LDS rows x 64 B; lane l lands at row l >> 2, physical slot l & 3, i.e. it
+    //      must fetch logical 16-byte slot (l & 3) ^ swz(row) of that row (igemm.hip's BK = 32 swizzle).
+    const int lrow = lane >> 2;
+    const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
+    // K piece p of a plane: sub-tile ks = p >> 1, half h = p & 1 (LDS rows 16 h .. 16 h + 15 of the sub-tile); LDS row
+    // 16 h + 4 a + b holds key 8 a + 4 h + b.  This wave's pieces are p = wave + NW i: h = wave & 1 for all of them.
+    const int kh = wave & 1;
+    const int key_l = 8 * (lrow >> 2) + 4 * kh + (lrow & 3);            // key (within the tile) this lane fetches
+    const frido_bf16* Kb = d.K + (int64_t)z * d.k_bs + lq * 8;
+    const int c_base = (int)blockIdx.y * (D / OS);       // first output channel of this workgroup
+    const frido_bf16* Vb = d.VT + (int64_t)z * d.vt_bs + (int64_t)(c_base + lrow) * d.ldvt + lq * 8;
+    const int ntiles = (d.Nk + G::BKV - 1) / G::BKV;
+
+    auto issue_k = [&](int j) {
+        int key = j * G::BKV + key_l;
+        key = key < d.Nk ? key : d.Nk - 1;               // rows past Nk: any valid row (their scores are masked)
+        const frido_bf16* src = Kb + (int64_t)key * d.ldk;
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int i = 0; i < (G::KP + NW - 1) / NW; ++i) {
+                const int piece = wave + NW * i;
+                if (piece < G::KP) {
+                    const int ks = piece >> 1;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.k_lo : 0) + ks * 32),
+                                                     (lptr_t)(smem + p * G::KPL + piece * 1024), 16, 0, 0);
+                }
+            }
+    };
+    auto issue_v = [&](int j) {
+        const frido_bf16* src = Vb + j * G::BKV;
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int i = 0; i < (G::VP + NW - 1) / NW; ++i) {
+                const int piece = wave + NW * i;
+                if (piece < G::VP)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.vt_lo : 0) + (int64_t)piece * 16 * d.ldvt),
+                                                     (lptr_t)(smem + G::KBUF + p * G::VPL + piece * 1024), 16, 0, 0);
+            }
+    };
+
+    // fragment read address inside a [16 rows][64 B] chunk: row r, logical slot g
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned frag = (unsigned)(r * 64 + ((g ^ ((4 - ((r >> 2) & 3)) & 3)) << 4));
+    const unsigned k_frag = lds0 + frag, v_frag = lds0 + G::KBUF + frag;
+
+    f32x4 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+    const float alpha = d.alpha;
+
+    issue_k(0);
+    for (int j = 0; j < ntiles; ++j) {
+        // ================= phase 1: S^T = K_j Q^T, online softmax =================
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // K_j visible; every wave has finished reading V^T_{j-1}
+        issue_v(j);
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        {
+            // bf16 mode: fragments of step ks + 1 are fetched under the MFMAs of step ks; bf16x3 mode has no registers to
+            // spare for a second fragment set (hi + lo planes of Q alone are 2 D / 8 VGPRs)
+            constexpr int NB = NS == 1 ? 2 : 1;
+            bf16x8 kf[NB][2][NS];                  // [buffer][half][plane]
+            if constexpr (NB == 2) {
+                kf[0][0][0] = lds_read128(k_frag);
+                kf[0][1][0] = lds_read128(k_frag + 1024);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if constexpr (NB == 2) {
+                    if (ks + 1 < KS) {
+                        kf[(ks + 1) & 1][0][0] = lds_read128(k_frag + (ks + 1) * 2048);
+                        kf[(ks + 1) & 1][1][0] = lds_read128(k_frag + (ks + 1) * 2048 + 1024);
+                        wait_lgkm<2>();
+                    } else {
+                        wait_lgkm<0>();
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+                        kf[0][0][p] = lds_read128(k_frag + p * G::KPL + ks * 2048);
+                        kf[0][1][p] = lds_read128(k_frag + p * G::KPL + ks * 2048 + 1024);
+                    }
+                    wait_lgkm<0>();
+                }
+                s0 = mma3<NS>(kf[ks & (NB - 1)][0], qf[ks], s0);
+                s1 = mma3<NS>(kf[ks & (NB - 1)][1], qf[ks], s1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // lane holds the scores of query r against keys 32 j + 8 g + {0..3} (s0) and + {4..7} (s1)
+        float sv[8] = {s0[0] * alpha, s0[1] * alpha, s0[2] * alpha, s0[3] * alpha, s1[0] * alpha, s1[1] * alpha, s1[2] * alpha, s1[3] * alpha};
+        if ((j + 1) * G::BKV > d.Nk) {             // ragged last tile (uniform branch)
+            const int k0 = j * G::BKV + 8 * g;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (k0 + i >= d.Nk) sv[i] = -1.0e30f;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        tmax = xor_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float corr = __expf(m_run - m_new);
+        float pv[8], rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pv[i] = __expf(sv[i] - m_new);
+            rs += pv[i];
+        }
+        rs = xor_sum(rs);
+        l_run = l_run * corr + rs;
+        m_run = m_new;
+        // P fragment (B operand of O^T += V^T P^T): k-slot 8 g + i <-> key 32 j + 8 g + i
+        bf16x8 pf[NS];
+        {
+            uint32_t h[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_bf16(pv[i], h[i], l[i]);
+            u32x4 ph = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            pf[0] = __builtin_bit_cast(bf16x8, ph);
+            if constexpr (NS == 2) {
+                u32x4 pl = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+                pf[1] = __builtin_bit_cast(bf16x8, pl);
+            }
+        }
+        if (__any(corr != 1.0f)) {                 // the running max moved for some query of this wave: rescale O^T
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                o[c][0] *= corr; o[c][1] *= corr; o[c][2] *= corr; o[c][3] *= corr;
+            }
+        }
+        // ================= phase 2: O^T += V^T_j P^T =================
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // V^T_j visible; every wave has finished reading K_j
+        if (j + 1 < ntiles) issue_k(j + 1);
+        {
+            constexpr int NB = NS == 1 ? 2 : 1;
+            bf16x8 vf[NB][NS];
+            if constexpr (NB == 2) vf[0][0] = lds_read128(v_frag);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if constexpr (NB == 2) {
+                    if (c + 1 < CT) {
+                        vf[(c + 1) & 1][0] = lds_read128(v_frag + (c + 1) * 1024);
+                        wait_lgkm<1>();
+                    } else {
+                        wait_lgkm<0>();
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) vf[0][p] = lds_read128(v_frag + p * G::VPL + c * 1024);
+                    wait_lgkm<0>();
+                }
+                o[c] = mma3<NS>(vf[c & (NB - 1)], pf, o[c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds O^T[c = 16 ct + 4 g + e][q = r]: four consecutive channels of its query per fragment ----
+    if (!q_ok) return;
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = c_base + c * 16 + g * 4;
+        float4 v = make_float4(o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv);
+        if (d.out_act) {                             // residual-stream form: O + bias + residual
+            if (d.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(d.bias + col);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
+            if (d.residual) {
+                const float4 rr = load_act4(d.residual, grow * d.ldr + col, d.act_bf16);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            const int64_t oo = grow * d.ld_act + col;
+            if (d.act_bf16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<frido_bf16*>(d.out_act) + oo) =
+                    make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
+            else
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo) = v;
+        } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            store_op4(d.out_op, d.out_lo, NS, grow * d.ldo + col, vv);
+        }
+    }
+}
+
+template <int D, int NS, int NW, int OS>
+int flash_launch(const FridoAttnSmall& d, hipStream_t s) {
+    constexpr int smem = FGeo<D, NS, NW, OS>::SMEM;
+    static std::atomic<uint64_t> done{0};           // > 64 KiB dynamic LDS is a per-device function attribute
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FRIDO_EHIP;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D, NS, NW, OS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                smem) != hipSuccess) {
+            frido_set_error("attn_flash: cannot set dynamic LDS size %d", smem);
+            return FRIDO_EHIP;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    const int blocks = d.B * ((d.Nq + NW * 16 - 1) / (NW * 16));
+    hipLaunchKernelGGL((flash_attn_kernel<D, NS, NW, OS>), dim3(blocks, OS), dim3(NW * 64), smem, s, d);
+    return frido_check_launch("attn_flash");
+}
+
+template <int D>
+int flash_dispatch(const FridoAttnSmall& d, hipStream_t s) {
+    if (d.nsplit == 2) return flash_launch<D, 2, 4, (D >= 512 ? 2 : 1)>(d, s);   // hi + lo planes of Q and P: one wave per SIMD
+    // 8 waves (128 queries) per workgroup halve the L2 -> LDS bytes per FLOP; 4 waves when that would leave CUs idle or the
+    // accumulators do not fit 256 registers
+    if constexpr (D <= 384) {
+        if ((int64_t)d.B * ((d.Nq + 127) / 128) >= 200) return flash_launch<D, 1, 8, 1>(d, s);
+    }
+    return flash_launch<D, 1, 4, 1>(d, s);
+}
+
+}  // namespace
+
+extern "C" int frido_attn_flash_supported(int32_t dd) { return dd == 128 || dd == 256 || dd == 384 || dd == 512 || dd == 576; }
+
+extern "C" int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->Q && d->K && d->VT && (d->out_op || d->out_act), "null pointer");
+    FRIDO_REQUIRE(!d->out_act || ((d->ld_act & 3) == 0 && (d->ldr & 3) == 0), "stream strides must be multiples of 4");
+    FRIDO_REQUIRE(d->B > 0 && d->Nq > 0 && d->Nk > 0, "empty problem");
+    FRIDO_REQUIRE(d->d == d->dv && frido_attn_flash_supported(d->d), "d = dv must be one of 128, 256, 384, 512, 576");
+    FRIDO_REQUIRE(d->ldvt >= ((d->Nk + 31) & ~31) && (d->ldvt & 7) == 0, "V^T rows must be zero-padded to a multiple of 32 keys");
+    FRIDO_REQUIRE((d->ldq & 7) == 0 && (d->ldk & 7) == 0 && (d->ldo & 3) == 0 && (d->q_lo & 7) == 0 && (d->k_lo & 7) == 0 &&
+                      (d->vt_lo & 7) == 0 && (d->out_lo & 3) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
+                  "strides and plane offsets must keep 16-byte alignment");
+    FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
+    hipStream_t st = (hipStream_t)s;
+    switch (d->d) {
+        case 128: return flash_dispatch<128>(*d, st);
+        case 256: return flash_dispatch<256>(*d, st);
+        case 384: return flash_dispatch<384>(*d, st);
+        case 512: return flash_dispatch<512>(*d, st);
+        default: return flash_dispatch<576>(*d, st);
+    }
+}

@@ -56,6 +56,7 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_ATTN_SMALL: return frido_attn_small(&op.u.attn_small, s);
         case FRIDO_OP_GN_FUSED: return frido_gn_fused(&op.u.gn_apply, s);
         case FRIDO_OP_COPY: return frido_copy(&op.u.copy, s);
+        case FRIDO_OP_ATTN_FLASH: return frido_attn_flash(&op.u.attn_small, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -234,6 +235,7 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_ATTN_SMALL: return sizeof(FridoAttnSmall);
         case FRIDO_OP_GN_FUSED: return sizeof(FridoGnApply);
         case FRIDO_OP_COPY: return sizeof(FridoCopy);
+        case FRIDO_OP_ATTN_FLASH: return sizeof(FridoAttnSmall);
         default: return -1;
     }
 }

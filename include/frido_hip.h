@@ -276,7 +276,7 @@ typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP_ATTN_FLASH, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -313,6 +313,13 @@ int frido_embed(const FridoEmbed* d, frido_stream_t s);
 int frido_to_u8(const FridoToU8* d, frido_stream_t s);
 int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s);
 int frido_copy(const FridoCopy* d, frido_stream_t s);
+/* Flash-style attention core for LONG key sequences on the same FridoAttnSmall descriptor (any Nk; d = dv in
+ * {128, 256, 384, 512, 576}; Nq arbitrary): online softmax over 32-key tiles, the [Nq][Nk] score matrix is never formed.
+ * Replaces the QK^T GEMM -> f32 scores -> softmax -> PV GEMM chain of frido/modules/attention.py:170-193 on the 32x32 /
+ * 64x64 planes and of the VQGAN AttnBlock (taming/modules/diffusionmodules/model.py:168-192: 4096 keys at 256^2, 16384 at
+ * 512^2).  frido_attn_flash_supported(d) tells whether a head dimension is instantiated. */
+int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s);
+int frido_attn_flash_supported(int32_t d);
 /* One-launch GroupNorm (statistics + apply) on a FridoGnApply descriptor whose `partials` is unused; bf16 stream only.
  * frido_gn_fused_chunk returns the channel-chunk width it would use (and the workgroup size), or 0 if the descriptor does
  * not qualify -- then gn_stats + gn_apply is the path. */

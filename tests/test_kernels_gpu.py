@@ -413,6 +413,7 @@ def test_attention_core(nsplit, B, Nq, Nk, d):
     from frido_amd import _lib
     fused = any(kind == _lib.OP_KINDS["FRIDO_OP_ATTN_SMALL"] for kind, _ in b.prog.ops)
     assert fused == (Nk <= 128 and Nq % 16 == 0)
+    assert not any(kind == _lib.OP_KINDS["FRIDO_OP_ATTN_FLASH"] for kind, _ in b.prog.ops)      # d = 64 / 96: not a flash head dim
     _run(b)
     ref = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1) @ v
     assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < (5e-5 if nsplit == 2 else 2e-2)
@@ -437,6 +438,53 @@ def test_attention_core_stream_output(nsplit, B, Nq, Nk, d):
     rq = r.to_f32().cpu()       # the residual as stored (bf16-rounded in bf16 mode)
     ref = (torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1) @ v).reshape(B * Nq, d) + bias + rq
     assert _relerr(o.to_f32().cpu(), ref) < (5e-5 if nsplit == 2 else 2e-2)
+
+
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("B,Nq,Nk,d", [(2, 1024, 1024, 384),      # U-Net 32x32 plane
+                                       (3, 256, 256, 576),        # U-Net 16x16 plane (4-wave variant, d > 512)
+                                       (1, 4096, 4096, 512),      # VQGAN AttnBlock at 256^2 (8- or 4-wave by grid size)
+                                       (16, 1024, 1024, 128),     # many workgroups: the 8-wave variant
+                                       (2, 200, 333, 256),        # ragged: Nq % 16 != 0, Nk % 32 != 0 (masked last tile)
+                                       (1, 16, 129, 128)])        # one query fragment, five key tiles
+def test_attention_flash(nsplit, B, Nq, Nk, d):
+    """Flash-style kernel (flash.hip) vs softmax(q k^T / sqrt(d)) v in fp64: operand output and residual-stream output."""
+    from frido_amd import _lib
+    from frido_amd.engine import pack_matrix, rup
+    q, k, v = _t("fq", B, Nq, d), _t("fk", B, Nk, d) * 1.5, _t("fv", B, Nk, d)
+    b = _builder(nsplit)
+    qo = pack_matrix(q.reshape(B * Nq, d).cuda(), nsplit)
+    ko = pack_matrix(k.reshape(B * Nk, d).cuda(), nsplit)
+    vto = pack_matrix(v.transpose(1, 2).reshape(B * d, Nk).cuda(), nsplit)            # [B*d][Nk padded to 32], pad = 0
+    assert vto.K == rup(Nk, 32)
+    o = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d)
+    bias, res = _t("fb", d), _t("fr", B * Nq, d)
+    bd = bias.cuda()
+    r = b.f32(B * Nq, d)
+    r.view().copy_(res.cuda())
+    o2 = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d, bias_ptr=bd.data_ptr(), residual=r, stream=True)
+    assert sum(kind == _lib.OP_KINDS["FRIDO_OP_ATTN_FLASH"] for kind, _ in b.prog.ops) == 2
+    _run(b)
+    ref = (torch.softmax(q.double() @ k.double().transpose(1, 2) * d ** -0.5, -1) @ v.double()).float()
+    tol = 5e-5 if nsplit == 2 else 2e-2
+    assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < tol
+    assert _relerr(o2.to_f32().cpu(), ref.reshape(B * Nq, d) + bias + r.to_f32().cpu()) < tol
+
+
+def test_attention_flash_online_softmax_rescale_branch():
+    """A key far above the rest in a LATE tile forces the running-max rescale of the accumulated O (rare on random data)."""
+    from frido_amd.engine import pack_matrix
+    B, Nq, Nk, d = 1, 64, 512, 128
+    q, k, v = _t("sq", B, Nq, d), _t("sk", B, Nk, d), _t("sv", B, Nk, d)
+    k[0, 300] = q[0, 5] * 3.0            # query 5 (and its neighbours, weakly) spike on key 300 = tile 9
+    k[0, 40] = q[0, 50] * 2.0            # an early spike: later tiles must NOT rescale
+    for nsplit in (2, 1):
+        b = _builder(nsplit)
+        o = b.attention(pack_matrix(q.reshape(Nq, d).cuda(), nsplit), d, pack_matrix(k.reshape(Nk, d).cuda(), nsplit), d,
+                        pack_matrix(v.transpose(1, 2).reshape(d, Nk).cuda(), nsplit), B, Nq, Nk, d)
+        _run(b)
+        ref = (torch.softmax(q.double() @ k.double().transpose(1, 2) * d ** -0.5, -1) @ v.double()).float()
+        assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < (5e-5 if nsplit == 2 else 2e-2)
 
 
 def test_geglu():

@@ -403,7 +403,11 @@ def test_apply_model_matches_oracle():
     """frido.py:1062-1160 -> DiffusionWrapper.forward (frido.py:1635-1654): tensor, list and dict conditioning."""
     from oracle.unet import unet_forward
     from frido_amd.synth import seeded_normal
-    model = _frido(UNET_SMALL, VQ_SMALL)
+    from frido_amd.models import instantiate_from_config
+    model = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion",
+                                         params=frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)))     # conditioning_key = crossattn
+    fill_module(model.model, "model.")
+    model = model.cuda().eval()
     usd = synth_sd(unet_holder(UNET_SMALL), "model.diffusion_model.")
     x = torch.from_numpy(seeded_normal("am:x", (2, 6, 16, 16)))
     c = torch.from_numpy(seeded_normal("am:c", (2, 5, 64)))
@@ -434,6 +438,8 @@ def test_sampling_script_call_sequence():
     fill_module(model.first_stage_model, "first_stage_model.")
     fill_module(model.cond_stage_model, "cond_stage_model.")
     model.scale_factor.copy_(torch.tensor([0.9, 1.1]))
+    from frido_amd.models import LitEma
+    model.model_ema = LitEma(model.model)          # the EMA shadow of the filled weights (a checkpoint would carry its own)
     model = model.cuda().eval()
     rng = np.random.default_rng(0)
     items = [{"image": np.tanh(rng.standard_normal((64, 64, 3))).astype(np.float32), "objects_bbox": g["tokens"][i],
@@ -512,8 +518,12 @@ def test_config1_full_width_end_to_end(run, S, precision):
     assert len(inter["x_inter"]) == int(g[f"{run}_nx"])
     rep = _e2e_report(f"config1/{run}/{precision}", model, g, run, samples, [3, 3])
     if precision == "bf16x3":
-        assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["frac_pix_gt_1e3"] < 0.02
-        assert rep["forced_pix_max"] < 1e-3
+        # north star: <= 1e-3 max-abs on decoded pixels.  Unconditional for the decoder (reference latent + codes); end to end
+        # it holds wherever no VQ code flipped -- one flipped code (a discontinuity) reaches every pixel through the decoder's
+        # four global attention blocks, so with flips only their rate is asserted
+        assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+        if rep["vq_flip_rate"] == 0:
+            assert rep["pix_max"] < 1e-3
     else:
         assert rep["latent_rel"] < E2E_BF16["latent_rel"] and rep["vq_flip_rate"] < E2E_BF16["vq_flip_rate"]
         assert rep["pix_p50"] < E2E_BF16["pix_p50"] and rep["pix_p99"] < E2E_BF16["pix_p99"]
@@ -521,7 +531,9 @@ def test_config1_full_width_end_to_end(run, S, precision):
 
 
 # bounds of the bf16 (benchmark) arithmetic end to end, = measured value x ~2 (see DESIGN.md §5 for the measurements)
-E2E_BF16 = dict(latent_rel=0.5, vq_flip_rate=0.5, pix_p50=0.5, pix_p99=2.0, forced_pix_max=0.5)
+# r02 measurements (gpurun_out/t_r02a.log): latent rel 0.85-1.2e-2, VQ flips 0.8-1.6 %, pixel error p50 1.4-2.1e-2 /
+# p99 0.21-0.28, decoder alone on identical codes 2.9-3.4e-2 max-abs
+E2E_BF16 = dict(latent_rel=3e-2, vq_flip_rate=4e-2, pix_p50=5e-2, pix_p99=0.6, forced_pix_max=8e-2)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
@@ -552,6 +564,8 @@ def test_config3_t2i_true_dims_plms_cfg(precision):
         rep = _e2e_report(f"config3/{run}/{precision}", model, g, run, samples, [4, 4])
         if precision == "bf16x3":
             assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+            if rep["vq_flip_rate"] == 0:
+                assert rep["pix_max"] < 1e-3
         else:
             assert rep["latent_rel"] < E2E_BF16["latent_rel"] and rep["forced_pix_max"] < E2E_BF16["forced_pix_max"]
 
