@@ -23,6 +23,9 @@ import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# pinned tile / split-K choices (frido_amd/tune.py): with the committed cache every run and every rank uses the same tiles, so
+# results are bitwise repeatable and no time goes into re-tuning; a rebuilt library (different size) starts a new cache
+os.environ.setdefault("FRIDO_TUNE_CACHE", os.path.join(REPO, "profiles", "tune_cache.json"))
 
 from frido_amd import configs, synth  # noqa: E402
 
@@ -70,10 +73,12 @@ def gemm_roofline(eng, stream_ptr, precision):
     achieved = flops / (t_gemm * 1e-3) / 1e12
     peak = 2500.0
     traffic, traffic_src = None, None
-    pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-        traffic = json.load(open(pmc)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
-        traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, reads x2)"
+    for tag in ("r02", "r01"):   # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        pmc = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, reads x2)"
+            break
     return dict(bound="mfma", kernel="igemm_kernel (implicit-GEMM conv3x3 + GEMM, v_mfma_f32_16x16x32_bf16)",
                 achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                 traffic_source=traffic_src, alg_bytes_per_launch=round(alg_bytes / n_gemm),
@@ -84,40 +89,77 @@ def gemm_roofline(eng, stream_ptr, precision):
                 mfma_passes=3 if precision == "bf16x3" else 1)
 
 
-def cpu_baseline(threads):
-    """Oracle (CPU restatement of the reference, fp32) on a bounded sample: B=1, two denoiser forwards per stage
-    and one decode, extrapolated linearly to DDIM-200 (cost is linear in the step count)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(threads, full_ddim50=False):
+    """The oracle (CPU restatement of the reference, fp32; pinned bit-exact to the reference by tests/test_oracle_golden.py) on
+    this host's cores, on a bounded sample of the benchmark's workload: B = 1 and B = 4, `threads` and 8
+    torch threads, a few timed denoiser forwards per stage + one decode each, extrapolated linearly to 2 x 200 forwards +
+    decode (the loop's cost is linear in the step count).  full_ddim50: additionally run a MEASURED DDIM-50 at B = 1."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle import samplers as S
     from oracle.unet import unet_forward
     from oracle.vqgan import vq_decode
     from frido_amd.models import PyUNetModel, VQModelInterface
-    torch.set_num_threads(threads)
     u = PyUNetModel(**configs.UNET_F8F4)
     usd = {"model.diffusion_model." + k: torch.from_numpy(synth.fill_tensor("model.diffusion_model." + k, v.shape))
            for k, v in u.state_dict().items()}
     v = VQModelInterface(**configs.VQ_F8F4, lossconfig=dict(target="taming.modules.losses.DummyLoss"))
     vsd = {"first_stage_model." + k: torch.from_numpy(synth.fill_tensor("first_stage_model." + k, t.shape))
            for k, t in v.state_dict().items()}
-    x = torch.from_numpy(synth.seeded_normal("cpu:x", (1, 6, 64, 64)))
-    ctx = torch.from_numpy(synth.seeded_normal("cpu:ctx", (1, 26, 640)))
-    t = torch.tensor([501])
-    ts = []
-    for s in (0, 1):
-        xin = x[:, :3 * (s + 1)]
-        unet_forward(usd, configs.UNET_F8F4, xin, t, ctx, s)          # warm
+    variants = []
+    for B, nthr, reps in ((1, threads, 3), (1, 8, 2), (4, threads, 1)):
+        if nthr > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nthr)
+        x = torch.from_numpy(synth.seeded_normal("cpu:x", (B, 6, 64, 64)))
+        ctx = torch.from_numpy(synth.seeded_normal("cpu:ctx", (B, 26, 640)))
+        t = torch.full((B,), 501)
+        ts = []
+        for s in (0, 1):
+            xin = x[:, :3 * (s + 1)]
+            if B == 1:
+                unet_forward(usd, configs.UNET_F8F4, xin, t, ctx, s)          # warm
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                unet_forward(usd, configs.UNET_F8F4, xin, t, ctx, s)
+            ts.append((time.perf_counter() - t0) / reps)
         t0 = time.perf_counter()
-        for _ in range(2):
-            unet_forward(usd, configs.UNET_F8F4, xin, t, ctx, s)
-            if time.perf_counter() - t0 > 8.0:
-                break
-        ts.append((time.perf_counter() - t0) / (_ + 1))
-    t0 = time.perf_counter()
-    vq_decode(vsd, configs.VQ_F8F4, x)
-    td = time.perf_counter() - t0
-    per_image = 200 * ts[0] + 200 * ts[1] + td
-    return dict(value=round(1.0 / per_image, 6), unit="images/s", cores=threads, kind="port",
-                sample=f"oracle fp32, B=1: 2 timed denoiser forwards per stage ({ts[0]:.3f}s / {ts[1]:.3f}s) + 1 decode "
-                       f"({td:.2f}s), extrapolated to 2x200 forwards + decode")
+        vq_decode(vsd, configs.VQ_F8F4, x)
+        td = time.perf_counter() - t0
+        loop = 200 * ts[0] + 200 * ts[1]
+        variants.append(dict(batch=B, threads=nthr, fwd_s=[round(ts[0], 4), round(ts[1], 4)], decode_s=round(td, 3),
+                             images_per_s=round(B / (loop + td), 6), loop_only_images_per_s=round(B / loop, 6)))
+    best = max(variants, key=lambda r: r["images_per_s"])
+    out = dict(value=best["images_per_s"], unit="images/s", cores=best["threads"], kind="port", cpu_model=_cpu_model(),
+               host_logical_cpus=os.cpu_count(), loop_only_value=best["loop_only_images_per_s"], variants=variants,
+               sample=f"oracle fp32 (CPU restatement pinned to the reference); best of {len(variants)} (batch, threads) variants = "
+                      f"B={best['batch']} on {best['threads']} torch threads: timed denoiser forwards per stage "
+                      f"({best['fwd_s'][0]}s / {best['fwd_s'][1]}s) + 1 decode ({best['decode_s']}s), extrapolated to 2x200 forwards "
+                      "+ decode; 256 torch threads collapse (130 s / forward) and are not used")
+    if full_ddim50:
+        torch.set_num_threads(threads)
+        ac = S.alphas_cumprod_f32(S.make_betas())
+        ctx = torch.from_numpy(synth.seeded_normal("cpu:ctx", (1, 26, 640)))
+        torch.manual_seed(23)
+        t0 = time.perf_counter()
+        z, _ = S.ddim_sample(lambda xx, tt, cc, s: unet_forward(usd, configs.UNET_F8F4, xx, tt, cc, s), ac, 50, (1, 6, 64, 64), ctx,
+                             [3, 3], [3, 3], 2, eta=1.0)
+        t1 = time.perf_counter()
+        S.decode_first_stage(lambda zz: vq_decode(vsd, configs.VQ_F8F4, zz), z, [1.0, 1.0], [3, 3])
+        t2 = time.perf_counter()
+        out["ddim50_measured"] = dict(batch=1, threads=threads, loop_s=round(t1 - t0, 2), decode_s=round(t2 - t1, 2),
+                                      images_per_s=round(1.0 / (t2 - t0), 6),
+                                      ddim200_extrapolated_images_per_s=round(1.0 / (4 * (t1 - t0) + (t2 - t1)), 6))
+    return out
 
 
 def main():
@@ -129,7 +171,9 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=200)
     ap.add_argument("--precision", default=os.environ.get("FRIDO_PRECISION", "bf16"), choices=["bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x3 (parity arithmetic) pass at N = 1")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-ddim50", action="store_true", help="also run a MEASURED DDIM-50 at B=1 on the CPU (~1 min)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,11 +215,23 @@ def main():
         img = one_step(args.warmup + k)
     fence()
     dt = time.perf_counter() - t0
+    per_rank = [dt]
     if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        allt = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt], device=dev, dtype=torch.float64))
+        per_rank = [float(t.item()) for t in allt]
+        dt = max(per_rank)                      # the slowest rank sets the job's time
     assert img.shape == (total, 3, 256, 256) and bool(torch.isfinite(img).all())
+    # the reference's own throughput definition (scripts/sample_diffusion.py:188-204): the sampling loop only, no decode
+    from frido_amd.samplers import DDIMSampler
+    unet = model.model.diffusion_model
+    fence()
+    t0 = time.perf_counter()
+    DDIMSampler(model).sample(S=args.ddim_steps, batch_size=B, shape=(unet.in_channels, unet.image_size, unet.image_size),
+                              conditioning=ctx, num_stage=unet.num_stage, eta=1.0, verbose=False, noise="philox", seed=999,
+                              sample0=lo, log_every_t=10 ** 9)
+    fence()
+    dt_loop = time.perf_counter() - t0
 
     if rank == 0:
         rt = model.model.diffusion_model.runtime()
@@ -192,11 +248,32 @@ def main():
                                    + (", RCCL all-gather of decoded images" if world > 1 else ""),
                        "global_batch": total, "denoiser_forwards_per_step": 2 * args.ddim_steps, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "loop_only_value": round(total / dt_loop, 4),         # sample_diffusion.py's `throughput`: sampler loop without decode
+            "per_rank_ms_per_step": [round(1e3 * t / args.steps, 2) for t in per_rank],
         }
+        e2e = os.path.join(REPO, "profiles", "r02_e2e_error.json")
+        if os.path.exists(e2e):                 # end-to-end error bounds of both arithmetic modes vs the reference (tests assert them)
+            out["e2e_error_vs_reference"] = json.load(open(e2e))
+        if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
+            # the SAME workload in the arithmetic the <= 1e-3 parity tests run in (bf16x3 = hi/lo bf16 planes, 3 MFMA passes,
+            # fp32-class): one warm-up + one timed pass
+            del model
+            torch.cuda.empty_cache()
+            m3 = build_model("bf16x3", dev)
+            sample_images(m3, ctx, S=args.ddim_steps, eta=1.0, seed=1, sample0=lo, noise="philox", total=total)
+            fence()
+            t0 = time.perf_counter()
+            sample_images(m3, ctx, S=args.ddim_steps, eta=1.0, seed=2, sample0=lo, noise="philox", total=total)
+            fence()
+            d3 = time.perf_counter() - t0
+            out["parity_mode"] = {"dtype": "bf16x3 (fp32-emulating, fp32 accumulate)", "value": round(total / d3, 4),
+                                  "unit": "images/s", "ms_per_step": round(1e3 * d3, 2), "steps": 1,
+                                  "note": "arithmetic of the <= 1e-3 max-abs parity tests (tests/test_model_gpu.py)"}
+            del m3
         if world == 1 and not args.no_cpu_baseline:
             # torch's intra-op pool stops scaling (and then collapses) long before a 128+-core host is full at B=1:
             # use 16 threads by default and say so in `cores`
-            out["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(16, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(16, os.cpu_count() or 1), full_ddim50=args.cpu_ddim50)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -15,6 +15,9 @@ UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample con
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
 ATTN_FLASH = os.environ.get("FRIDO_ATTN_FLASH", "1") != "0"       # flash-style kernel for long key sequences (flash.hip)
+# below this many keys the score matrix is small and the batched GEMM -> softmax -> GEMM chain fills the chip better than
+# one workgroup per 64 queries (measured at B = 16: 256 keys x d = 576: 37 us vs 49 us; 1024 keys x d = 384: 102 vs 82 us)
+ATTN_FLASH_MIN_KEYS = int(os.environ.get("FRIDO_ATTN_FLASH_MIN_KEYS", "512"))
 
 
 class Builder:
@@ -58,6 +61,15 @@ class Builder:
         self._persist.append(t)
         return t
 
+    def h64(self, name):
+        """Weight as a float64 HOST matrix [N][K]: the plan-time algebra (folded projections) is done on the CPU so that the
+        device trace holds nothing but this library's kernels (no rocBLAS / Tensile fp64 GEMMs)."""
+        w = self.w[name].detach().to("cpu", torch.float64)
+        return w.reshape(w.shape[0], -1) if w.dim() > 1 else w
+
+    def to_dev(self, t):
+        return t.to(torch.float32).contiguous().to(self.device)
+
     def dev_f32(self, name):
         t = self.w[name]
         if t.dtype != torch.float32 or not t.is_contiguous():
@@ -88,14 +100,11 @@ class Builder:
         sum to one.  Returns (operand of W_o W_v, device pointer of the folded bias); the product is formed in float64."""
         key = ("vo", v_name, o_name)
         if key not in self._wcache:
-            wv = self.w[v_name + ".weight"].double()
-            wv = wv.reshape(wv.shape[0], -1)
-            wo = self.w[o_name + ".weight"].double()
-            wo = wo.reshape(wo.shape[0], -1)
-            bias = self.w[o_name + ".bias"].double().clone() if (o_name + ".bias") in self.w else torch.zeros(wo.shape[0], dtype=torch.float64, device=wo.device)
+            wv, wo = self.h64(v_name + ".weight"), self.h64(o_name + ".weight")
+            bias = self.h64(o_name + ".bias").clone() if (o_name + ".bias") in self.w else torch.zeros(wo.shape[0], dtype=torch.float64)
             if (v_name + ".bias") in self.w:
-                bias += wo @ self.w[v_name + ".bias"].double()
-            self._wcache[key] = (pack_matrix((wo @ wv).float(), self.nsplit), bias.float().contiguous())
+                bias += wo @ self.h64(v_name + ".bias")
+            self._wcache[key] = (pack_matrix(self.to_dev(wo @ wv), self.nsplit), self.to_dev(bias))
         wop, bias = self._wcache[key]
         return wop, bias.data_ptr()
 
@@ -104,14 +113,13 @@ class Builder:
         bf16-stream mode only (a2 is a bf16 activation read as a second A operand along K)."""
         key = ("chain", first, second)
         if key not in self._wcache:
-            wf, ws = self.w[first + ".weight"].double(), self.w[second + ".weight"].double()
-            wf, ws = wf.reshape(wf.shape[0], -1), ws.reshape(ws.shape[0], -1)
-            bias = ws @ self.w[first + ".bias"].double() + self.w[second + ".bias"].double()
+            wf, ws = self.h64(first + ".weight"), self.h64(second + ".weight")
+            bias = ws @ self.h64(first + ".bias") + self.h64(second + ".bias")
             k1, k2 = rup(wf.shape[1], 64), rup(ws.shape[1], 64)
-            w = torch.zeros((ws.shape[0], k1 + k2), dtype=torch.float64, device=ws.device)
+            w = torch.zeros((ws.shape[0], k1 + k2), dtype=torch.float64)
             w[:, :wf.shape[1]] = ws @ wf
             w[:, k1:k1 + ws.shape[1]] = ws
-            self._wcache[key] = (pack_matrix(w.float(), self.nsplit), bias.float().contiguous(), k1, k2)
+            self._wcache[key] = (pack_matrix(self.to_dev(w), self.nsplit), self.to_dev(bias), k1, k2)
         wop, bias, k1, k2 = self._wcache[key]
         assert getattr(a2, "bf16", False) and a.K == k1 and a2.C == k2, (a.K, k1, a2.C, k2)
         M = a.rows * getattr(a, "batch", 1)
@@ -128,17 +136,14 @@ class Builder:
         (only valid without a query bias: the projected keys can be cached and the queries are the raw input rows)."""
         key = ("qk", q_name, k_name, side)
         if key not in self._wcache:
-            wq = self.w[q_name + ".weight"].double()
-            wq = wq.reshape(wq.shape[0], -1)
-            wk = self.w[k_name + ".weight"].double()
-            wk = wk.reshape(wk.shape[0], -1)
-            bq = self.w[q_name + ".bias"].double() if (q_name + ".bias") in self.w else None
+            wq, wk = self.h64(q_name + ".weight"), self.h64(k_name + ".weight")
+            bq = self.h64(q_name + ".bias") if (q_name + ".bias") in self.w else None
             if side == "q":
-                bias = (wk.t() @ bq).float().contiguous() if bq is not None else None
-                self._wcache[key] = (pack_matrix((wk.t() @ wq).float(), self.nsplit), bias)
+                bias = self.to_dev(wk.t() @ bq) if bq is not None else None
+                self._wcache[key] = (pack_matrix(self.to_dev(wk.t() @ wq), self.nsplit), bias)
             else:
                 assert bq is None, "a query bias cannot be folded into the key side"
-                self._wcache[key] = (pack_matrix((wq.t() @ wk).float(), self.nsplit), None)
+                self._wcache[key] = (pack_matrix(self.to_dev(wq.t() @ wk), self.nsplit), None)
         wop, bias = self._wcache[key]
         return wop, (bias.data_ptr() if bias is not None else None)
 
@@ -212,21 +217,21 @@ class Builder:
         (a, b) = (0,0), (0,1), (1,0), (1,1) (top / left padding of a phase: 1 - a, 1 - b)."""
         key = ("up2", wname)
         if key not in self._wcache:
-            w = self.w[wname + ".weight"].double()            # [Cout][Cin][3][3]
+            w = self.w[wname + ".weight"].detach().to("cpu", torch.float64)            # [Cout][Cin][3][3]
             co, ci = w.shape[:2]
             cp = rup(ci, 32)
             rows = {0: [w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 1: [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]}     # [ty] -> [Cout][Cin][3(kx)]
             mats = []
             for a_ in (0, 1):
                 for b_ in (0, 1):
-                    wk = torch.zeros((co, 2, 2, cp), dtype=torch.float64, device=w.device)
+                    wk = torch.zeros((co, 2, 2, cp), dtype=torch.float64)
                     for ty in (0, 1):
                         r = rows[a_][ty]                      # [Cout][Cin][3]
                         cols = [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if b_ == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
                         for tx in (0, 1):
                             wk[:, ty, tx, :ci] = cols[tx]
                     mats.append(wk.reshape(co, -1))
-            self._wcache[key] = (pack_matrix(torch.cat(mats, dim=0).float(), self.nsplit), cp)      # [4 Cout][4 Cin_pad]
+            self._wcache[key] = (pack_matrix(self.to_dev(torch.cat(mats, dim=0)), self.nsplit), cp)      # [4 Cout][4 Cin_pad]
         return self._wcache[key]
 
     def upsample_conv(self, a, B, Hs, Ws, wname):
@@ -394,7 +399,8 @@ class Builder:
         Np = rup(Nk, 32)
         aligned = ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0
         small = Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and aligned
-        flash = (not small and ATTN_FLASH and aligned and _lib.lib().frido_attn_flash_supported(d))
+        flash = (not small and ATTN_FLASH and aligned and _lib.lib().frido_attn_flash_supported(d)
+                 and (Nk >= ATTN_FLASH_MIN_KEYS or Nk > 4096))
         if small or flash:
             # one launch, scores stay on chip: the short-key kernel (cross-attention, 8x8 planes) or the flash-style kernel
             kind = "FRIDO_OP_ATTN_SMALL" if small else "FRIDO_OP_ATTN_FLASH"

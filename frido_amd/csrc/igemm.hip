@@ -56,7 +56,10 @@ struct Geo {
     // 16384x384x384).  8-wave tiles own the CU, so they take what fits.
     static constexpr int D8 = 147456 / STAGE > 6 ? 6 : 147456 / STAGE;
     static constexpr int D = NW == 8 ? D8 : ((4 * STAGE <= 98304 && NS == 1) ? 4 : 3);
-    static constexpr int EPI = NW * 16 * (BN / 2 + 4) * 4;  // epilogue transpose slabs (one per wave)
+    static constexpr int SLABS = NW * 16 * (BN / 2 + 4) * 4;   // epilogue transpose slabs (one per wave)
+    // + the bf16 residual sub-tile of every wave, DMA'd into the idle ring at the start of the epilogue (bf16 mode)
+    static constexpr bool RSTAGE = NS == 1 && SLABS + BM * BN * 2 <= 163840;
+    static constexpr int EPI = SLABS + (RSTAGE ? BM * BN * 2 : 0);
     static constexpr int SMEM = D * STAGE > EPI ? D * STAGE : EPI;
     static_assert(SMEM <= 163840, "LDS budget");
 };
@@ -73,7 +76,7 @@ __device__ __forceinline__ void wait_tail(int rem) {
 }
 
 // ---- epilogue (shared by the ring kernel and the patch-staged 3x3 kernel) --------------------------------------
-template <int BM, int BN, int NS, int WM>
+template <int BM, int BN, int NS, int WM, bool RSTAGE>
 __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[BM / WM / 16][BN / 2 / 16], unsigned char* smem,
                                               int m0, int n0, int wave, int lane, int zo, int zi, int kz) {
     constexpr int WN = 2, TM = BM / WM / 16, TN = BN / WN / 16;
@@ -130,6 +133,32 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         const float4 t0 = *reinterpret_cast<const float4*>(d.bias + ncol), t1 = *reinterpret_cast<const float4*>(d.bias + ncol + 4);
         bia[0] = t0.x; bia[1] = t0.y; bia[2] = t0.z; bia[3] = t0.w; bia[4] = t1.x; bia[5] = t1.y; bia[6] = t1.z; bia[7] = t1.w;
     }
+    // Sampler mode (rows_per_vec >= 2^29): ONE timestep vector serves every row of the launch, so it is a second bias.  Read
+    // per pass it was a dependent L2 round trip in front of every store (the epilogue of a 64^2 conv took 14 us of its 57).
+    const bool rv_hoist = d.rowvec && d.rows_per_vec >= (1 << 29) && !(d.flags & 2);
+    if (fast && rv_hoist && !wsp && !d.geglu && lane_on8 && ncol < d.N) {
+        const float* rp = d.rowvec + (int64_t)vstep * d.ldv + ncol;
+        const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
+        bia[0] += t0.x; bia[1] += t0.y; bia[2] += t0.z; bia[3] += t0.w; bia[4] += t1.x; bia[5] += t1.y; bia[6] += t1.z; bia[7] += t1.w;
+    }
+    // bf16 residual: this wave's [WR][WC] sub-tile goes L2 -> LDS by DMA right now (the ring is idle, no VGPRs, nothing waits
+    // for it until the first slab has been transposed) instead of one dependent global load per pass.
+    const bool res_stage = RSTAGE && fast && d.residual && d.res_bf16 && !wsp && !d.geglu && !(d.flags & 1);
+    constexpr int RS_BASE = WM * WN * 16 * EPS * 4;                       // behind every wave's transpose slab
+    unsigned char* rstage = smem + RS_BASE + wave * (WR * WC * 2);
+    if (res_stage) {
+        constexpr int NI = WR * WC / 512;                                  // 1-KiB pieces of the sub-tile
+        const frido_bf16* rbase = reinterpret_cast<const frido_bf16*>(d.residual) + rs_base;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int L = k * 64 + lane, row = L / LPR8, c8 = L - row * LPR8;
+            int m = m0 + wm * WR + row, n = nbase + c8 * 8;
+            m = m < d.M ? m : d.M - 1;
+            n = n + 8 <= d.N ? n : 0;                                      // columns past N: any valid address (masked later)
+            __builtin_amdgcn_global_load_lds((gptr_t)(rbase + (int64_t)m * d.ldr + n), (lptr_t)(rstage + k * 1024), 16, 0, 0);
+        }
+    }
+    bool res_wait = res_stage;
     // GEGLU (attention.py:42-44): the projection's rows are packed so that 16-column blocks alternate [a | gate]; a value and
     // its gate are then the SAME element of adjacent accumulator fragments, so a * gelu(gate) is formed in registers and only
     // the WC/2 outputs go through the LDS transposition (half the slab traffic of transposing both).
@@ -184,6 +213,10 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = sel[j][e];
+        if (res_wait) {                     // the staged residual tile has landed (this wave's own DMA: no barrier needed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            res_wait = false;
+        }
         if (!fast) {
             // generic element-wise path (ragged N or unaligned strides: the 3-channel output conv, odd test shapes).  Rolled
             // and scalar on purpose: unrolled per-element fallbacks inside the vector path tripled the kernel's code size.
@@ -226,7 +259,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             float rb = d.row_bias ? d.row_bias[m] : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + bia[e] + rb;
-            if (d.rowvec) {
+            if (d.rowvec && !rv_hoist) {
                 const float* rp = d.rowvec + (int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n;
                 const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
                 v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
@@ -246,7 +279,8 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             if (d.residual) {
                 const int64_t ro = rs_base + (int64_t)m * d.ldr + n;
                 if (d.res_bf16) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const frido_bf16*>(d.residual) + ro);
+                    const uint4 u = res_stage ? *reinterpret_cast<const uint4*>(rstage + ((i * 16 + r) * LPR8 + (ec8 >> 3)) * 16)
+                                              : *reinterpret_cast<const uint4*>(reinterpret_cast<const frido_bf16*>(d.residual) + ro);
                     v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
                     v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
                     v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
@@ -524,7 +558,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         buf = buf + 1 == D ? 0 : buf + 1;
     }
 
-    tile_epilogue<BM, BN, NS, WM>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz);
+    tile_epilogue<BM, BN, NS, WM, G::RSTAGE>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz);
 }
 
 // =====================================================================================================================
@@ -560,7 +594,9 @@ struct PGeo {
     static constexpr int PBUF = PCH * 1024, BSTAGE = BN * 64, DB = NW == 8 ? 6 : 3;
     static constexpr int BCH = BN / 16, LPBMAX = (BCH + NW - 1) / NW;   // weight chunks per tap; pieces per wave (upper bound)
     static constexpr int B0 = 2 * PBUF;
-    static constexpr int EPI = NW * 16 * (BN / 2 + 4) * 4;
+    static constexpr int SLABS = NW * 16 * (BN / 2 + 4) * 4;
+    static constexpr bool RSTAGE = true;
+    static constexpr int EPI = SLABS + BM * BN * 2;           // transpose slabs + staged bf16 residual tile
     static constexpr int SMEM = B0 + DB * BSTAGE > EPI ? B0 + DB * BSTAGE : EPI;
     static_assert(BN == 192 && (NW == 8 || NW == 4), "12 weight chunks: 8 + 4 (8 waves) or 3 x 4 (4 waves)");
     static_assert(SMEM <= 163840, "LDS budget");
@@ -901,7 +937,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
         cx.A2b = A2b; cx.Kc = d.K; cx.nc2 = gridDim.z == 1 ? nc2 : 0;
         cx.arow0 = m0 + wave * 16 + (lane >> 2); cx.lda2 = d.lda2; cx.frow0 = wm * (BM / WM) + frow;
         patch_static_loop<BN, NW, HAS2>(cx, acc, c_begin, nch < nc1 ? nch : nc1);
-        tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
+        tile_epilogue<BM, BN, 1, WM, true>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
         return;
     }
     // ---- prologue ----
@@ -980,7 +1016,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
             markp_cur = markp_nxt;
         }
     }
-    tile_epilogue<BM, BN, 1, WM>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
+    tile_epilogue<BM, BN, 1, WM, true>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
 }
 
 // split-K reduction + epilogue, 8 columns per thread (16-byte accesses; N % 8 == 0 and 8-element aligned strides)

@@ -13,6 +13,8 @@ import torch
 
 from . import _lib
 
+import os
+GEMM_FLAGS = int(os.environ.get("FRIDO_GEMM_FLAGS", "0"))     # FridoGemm.flags A/B switches (include/frido_hip.h)
 BF16X3 = 2   # nsplit: hi + residual plane, 3 MFMAs per product (≈ fp32 accuracy)
 BF16 = 1     # nsplit: plain bf16 operands
 
@@ -200,7 +202,7 @@ class Prog:
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
         kw = dict(M=M, N=N, K=K, batch=batch, nsplit=self.nsplit, A=ap, a_lo=alo if a_lo is None else a_lo,
                   a_bs=a_bs, lda=lda if lda is not None else K, B=bp, b_lo=blo if b_lo is None else b_lo,
-                  b_bs=b_bs, ldb=ldb if ldb is not None else K, alpha=alpha, act=act, tile=tile, geglu=geglu, batch_inner=batch_inner, a_bs2=a_bs2, b_bs2=b_bs2,
+                  b_bs=b_bs, ldb=ldb if ldb is not None else K, alpha=alpha, act=act, tile=tile, geglu=geglu, batch_inner=batch_inner, a_bs2=a_bs2, b_bs2=b_bs2, flags=GEMM_FLAGS,
                   of_bs2=of_bs2, oo_bs2=oo_bs2)
         if conv:
             kw.update(conv=1, **conv)

@@ -49,3 +49,53 @@ def test_all_gather_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+WORKER2 = r"""
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import frido_amd.samplers as smp
+from frido_amd.pipeline import shard_range, sample_images
+
+class StubSampler:                      # stands in for the HIP sampler: a sample depends only on (seed, GLOBAL index, its cond)
+    def __init__(self, model, **kw):
+        pass
+    def sample(self, S, batch_size, shape, conditioning, num_stage, eta, verbose, unconditional_guidance_scale,
+               unconditional_conditioning, noise, seed, sample0, log_every_t):
+        assert noise == "philox" and conditioning.shape[0] == batch_size
+        idx = torch.arange(sample0, sample0 + batch_size, dtype=torch.float32)
+        z = (seed * 1000 + idx).view(-1, 1, 1, 1).expand(batch_size, *shape) + conditioning.mean(dim=(1, 2)).view(-1, 1, 1, 1)
+        return z.contiguous(), {}
+smp.DDIMSampler = smp.PLMSSampler = StubSampler
+
+class Model:
+    def __init__(self):
+        self.model = types.SimpleNamespace(diffusion_model=types.SimpleNamespace(in_channels=6, image_size=4, num_stage=2))
+    def decode_first_stage(self, z):
+        return z[:, :3] * 2.0
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+for total in (8, 7, 3):                  # equal shards, ragged shards, fewer samples than 2 x world
+    cond_all = torch.arange(total, dtype=torch.float32).view(total, 1, 1).expand(total, 5, 4) * 0.25
+    lo, hi = shard_range(total, rank, world)
+    img = sample_images(Model(), cond_all[lo:hi].contiguous(), S=4, seed=3, sample0=lo, total=total)
+    ref = sample_images(Model(), cond_all, S=4, seed=3, sample0=0, total=total, gather=False)     # what ONE rank would produce
+    assert img.shape == (total, 3, 4, 4) and torch.equal(img, ref), (rank, total)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sample_images_shard_logic_world_size_2_gloo(tmp_path):
+    """The REAL pipeline.sample_images (contiguous shard, sample0 = global index of the shard's first sample, one all-gather
+    with ragged shards padded) on two gloo ranks with a stub sampler / decoder: the joined batch equals the single-rank
+    result, i.e. it is invariant to the number of ranks."""
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2 % REPO)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

@@ -447,9 +447,10 @@ def test_attention_core_stream_output(nsplit, B, Nq, Nk, d):
                                        (16, 1024, 1024, 128),     # many workgroups: the 8-wave variant
                                        (2, 200, 333, 256),        # ragged: Nq % 16 != 0, Nk % 32 != 0 (masked last tile)
                                        (1, 16, 129, 128)])        # one query fragment, five key tiles
-def test_attention_flash(nsplit, B, Nq, Nk, d):
+def test_attention_flash(nsplit, B, Nq, Nk, d, monkeypatch):
     """Flash-style kernel (flash.hip) vs softmax(q k^T / sqrt(d)) v in fp64: operand output and residual-stream output."""
-    from frido_amd import _lib
+    from frido_amd import _lib, builder as builder_mod
+    monkeypatch.setattr(builder_mod, "ATTN_FLASH_MIN_KEYS", 0)      # the dispatcher keeps short sequences on the GEMM chain
     from frido_amd.engine import pack_matrix, rup
     q, k, v = _t("fq", B, Nq, d), _t("fk", B, Nk, d) * 1.5, _t("fv", B, Nk, d)
     b = _builder(nsplit)
@@ -471,9 +472,11 @@ def test_attention_flash(nsplit, B, Nq, Nk, d):
     assert _relerr(o2.to_f32().cpu(), ref.reshape(B * Nq, d) + bias + r.to_f32().cpu()) < tol
 
 
-def test_attention_flash_online_softmax_rescale_branch():
+def test_attention_flash_online_softmax_rescale_branch(monkeypatch):
     """A key far above the rest in a LATE tile forces the running-max rescale of the accumulated O (rare on random data)."""
     from frido_amd.engine import pack_matrix
+    from frido_amd import builder as builder_mod
+    monkeypatch.setattr(builder_mod, "ATTN_FLASH_MIN_KEYS", 0)
     B, Nq, Nk, d = 1, 64, 512, 128
     q, k, v = _t("sq", B, Nq, d), _t("sk", B, Nk, d), _t("sv", B, Nk, d)
     k[0, 300] = q[0, 5] * 3.0            # query 5 (and its neighbours, weakly) spike on key 300 = tile 9

@@ -36,7 +36,7 @@ def table(prog, sp, title, top=None):
             desc = f"B={st.B} HW={st.HW} C={st.C1 + st.C2} S={st.nsplit_px}" + (" spade" if n in ("GN_APPLY", "GN_FUSED") and st.gamma else "")
         if n == "LAYERNORM":
             desc = f"rows={st.rows} C={st.C}"
-        if n == "ATTN_SMALL":
+        if n in ("ATTN_SMALL", "ATTN_FLASH"):
             desc = f"B={st.B} Nq={st.Nq} Nk={st.Nk} d={st.d}"
             fl = 4.0 * st.B * st.Nq * st.Nk * st.d
         if n == "SOFTMAX":
