@@ -76,10 +76,20 @@ def gemm_roofline(eng, stream_ptr, precision):
     for tag in ("r02", "r01"):   # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
         pmc = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
-            traffic_src = f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, reads x2)"
+            blob = json.load(open(pmc))
+            fam = [blob[k] for k in ("igemm_kernel", "conv3x3_patch_kernel") if k in blob]      # the two kernels of the family
+            if fam:
+                traffic = round(sum(e["hbm_bytes_per_launch"] * e["launches"] for e in fam) / sum(e["launches"] for e in fam))
+                traffic_src = (f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, reads x2; "
+                               "launch-weighted mean over igemm_kernel + conv3x3_patch_kernel)")
             break
-    return dict(bound="mfma", kernel="igemm_kernel (implicit-GEMM conv3x3 + GEMM, v_mfma_f32_16x16x32_bf16)",
+    mfma_busy = None
+    pm = os.path.join(REPO, "profiles", "r02_pmc_mfma.json")
+    if os.path.exists(pm):       # matrix-pipe busy share of the two kernels (SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_sq.py)
+        blob = json.load(open(pm))
+        mfma_busy = {k: blob[k].get("mfma_busy_frac") for k in ("igemm_kernel", "conv3x3_patch_kernel") if k in blob}
+    return dict(bound="mfma", kernel="igemm_kernel + conv3x3_patch_kernel (implicit-GEMM conv3x3 / GEMM family, v_mfma_f32_16x16x32_bf16)",
+                mfma_busy_pmc=mfma_busy,
                 achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                 traffic_source=traffic_src, alg_bytes_per_launch=round(alg_bytes / n_gemm),
                 launches=n_gemm, avg_launch_us=round(1e3 * t_gemm / n_gemm, 2),

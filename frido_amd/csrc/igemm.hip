@@ -1268,6 +1268,11 @@ static int ensure_device_attrs() {
     return rc;
 }
 
+extern "C" int64_t frido_gemm_workspace_bytes(const FridoGemm* d) {
+    if (!d || d->splitk <= 1) return 0;
+    return (int64_t)d->splitk * d->M * d->N * (int64_t)sizeof(float);
+}
+
 extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     FRIDO_REQUIRE(dp != nullptr, "null descriptor");
     const FridoGemm& d = *dp;

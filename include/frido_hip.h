@@ -295,6 +295,10 @@ typedef struct FridoOp {
 
 /* ---- single-op launchers ---- */
 int frido_gemm(const FridoGemm* d, frido_stream_t s);
+/* Bytes of the split-K workspace `ws` a descriptor needs (0 when splitk <= 1): splitk * M * N floats.  The caller owns the
+ * buffer (one per stream is enough: launches on a stream are ordered); a host that is not the bundled Python runtime sizes
+ * it with this call instead of reading frido_amd/tune.py. */
+int64_t frido_gemm_workspace_bytes(const FridoGemm* d);
 int frido_gn_stats(const FridoGnStats* d, frido_stream_t s);
 int frido_gn_apply(const FridoGnApply* d, frido_stream_t s);
 int frido_layernorm(const FridoLayerNorm* d, frido_stream_t s);

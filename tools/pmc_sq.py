@@ -4,8 +4,10 @@ the derived ratios DESIGN.md quotes.   python tools/pmc_sq.py <dir> [<dir> ...] 
 
 Units (MI355X_MICROARCH.md §Per-instruction cycle constants): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
 per wave, summed over all waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, summed over the chip's 1024 SIMDs;
-GRBM_GUI_ACTIVE = shader-clock cycles the dispatch was resident.  Hence
-    mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * GRBM_GUI_ACTIVE)       share of SIMD-cycles the matrix pipe is busy
+GRBM_GUI_ACTIVE = shader-clock cycles the dispatch was resident, summed over the 8 XCDs (cross-check: the patch-staged conv's
+18.0e9 MFMA-busy cycles = its MFMA count x 16 cycles per v_mfma_f32_16x16x32_bf16; its GUI_ACTIVE / 8 = its average duration x
+the ~2.3 GHz clock rocm-smi shows under load).  Hence
+    mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * GRBM_GUI_ACTIVE / 8)   share of SIMD-cycles the matrix pipe is busy
     wait_any_frac    = SQ_WAIT_ANY / SQ_WAVE_CYCLES                              waves parked on s_waitcnt / s_barrier
     wait_inst_frac   = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                         waves stalled at issue (dependency / pipe)
     active_frac      = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
@@ -41,7 +43,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", kv[
     n = max(calls[k].values())
     e = dict(launches=n, counters={c: round(x) for c, x in sorted(v.items())})
     # counters of different passes are sums over the same dispatch sequence, so their ratios are well defined
-    e["mfma_busy_frac"] = ratio(v, "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", 1024.0)
+    e["mfma_busy_frac"] = ratio(v, "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", 128.0)
+    if v.get("GRBM_GUI_ACTIVE"):
+        e["avg_cycles_per_launch"] = round(v["GRBM_GUI_ACTIVE"] / 8.0 / calls[k]["GRBM_GUI_ACTIVE"])
     e["wait_any_frac"] = ratio(v, "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")
     e["wait_inst_frac"] = ratio(v, "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES")
     e["active_frac"] = ratio(v, "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES")
