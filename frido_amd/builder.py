@@ -21,12 +21,13 @@ ATTN_FLASH_MIN_KEYS = int(os.environ.get("FRIDO_ATTN_FLASH_MIN_KEYS", "512"))
 
 
 class Builder:
-    def __init__(self, device, nsplit, weights=None):
+    def __init__(self, device, nsplit, weights=None, ws_tag=""):
         self.device = torch.device(device)
         self.nsplit = nsplit
+        self.ws_tag = ws_tag
         self.w = weights or {}          # name -> f32 tensor on device (reference state_dict naming)
         self.pool = Pool(self.device)
-        self.prog = Prog(self.device, nsplit)
+        self.prog = Prog(self.device, nsplit, ws_tag)
         self._wcache = {}
         self._persist = []              # tensors that must outlive the builder's programs
         # bf16 mode keeps the residual stream itself in bf16 (it then doubles as the MFMA operand: no pack passes);
@@ -35,7 +36,7 @@ class Builder:
 
     # ---- programs ------------------------------------------------------------------------------
     def new_prog(self):
-        self.prog = Prog(self.device, self.nsplit)
+        self.prog = Prog(self.device, self.nsplit, self.ws_tag)
         self.prog.keep.append(self)
         return self.prog
 

@@ -23,6 +23,7 @@
 //   * bf16x3 mode (NS = 2): Q, K, V^T and P carry hi + lo bf16 planes, products are hi*hi + hi*lo + lo*hi in f32.
 #include "common.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -72,7 +73,11 @@ struct FGeo {
     static constexpr int KPL = BKV * D * 2;              // bytes of one K plane of a tile  ([KS][32 rows][64 B])
     static constexpr int VPL = D / OS * BKV * 2;         // bytes of one V^T plane of a tile ([D / OS rows][64 B])
     static constexpr int KBUF = NS * KPL, VBUF = NS * VPL;
-    static constexpr int SMEM = KBUF + VBUF;
+    // two tiles in LDS where they fit: K / V^T of tile j + 1 stream in during ALL of tile j (one barrier per tile).  With one
+    // tile (bf16x3 mode at d >= 384) the two phases of a tile cover each other's DMA instead.
+    static constexpr bool DBUF = 2 * (KBUF + VBUF) <= 163840;
+    static constexpr int TILE = KBUF + VBUF;
+    static constexpr int SMEM = (DBUF ? 2 : 1) * TILE;
     static constexpr int KP = KS * 2, VP = D / 16 / OS;  // 1-KiB DMA pieces per plane
     static_assert(D % (32 * OS) == 0 && SMEM <= 163840, "LDS budget");
     static_assert(NW % 2 == 0, "a wave's K pieces all belong to one 16-row half");
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
     const frido_bf16* Vb = d.VT + (int64_t)z * d.vt_bs + (int64_t)(c_base + lrow) * d.ldvt + lq * 8;
     const int ntiles = (d.Nk + G::BKV - 1) / G::BKV;
 
-    auto issue_k = [&](int j) {
+    auto issue_k = [&](int j, int buf = 0) {
         int key = j * G::BKV + key_l;
         key = key < d.Nk ? key : d.Nk - 1;               // rows past Nk: any valid row (their scores are masked)
         const frido_bf16* src = Kb + (int64_t)key * d.ldk;
@@ -140,11 +145,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
                 if (piece < G::KP) {
                     const int ks = piece >> 1;
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.k_lo : 0) + ks * 32),
-                                                     (lptr_t)(smem + p * G::KPL + piece * 1024), 16, 0, 0);
+                                                     (lptr_t)(smem + buf * G::TILE + p * G::KPL + piece * 1024), 16, 0, 0);
                 }
             }
     };
-    auto issue_v = [&](int j) {
+    auto issue_v = [&](int j, int buf = 0) {
         const frido_bf16* src = Vb + j * G::BKV;
 #pragma unroll
         for (int p = 0; p < NS; ++p)
@@ -153,14 +158,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
                 const int piece = wave + NW * i;
                 if (piece < G::VP)
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.vt_lo : 0) + (int64_t)piece * 16 * d.ldvt),
-                                                     (lptr_t)(smem + G::KBUF + p * G::VPL + piece * 1024), 16, 0, 0);
+                                                     (lptr_t)(smem + buf * G::TILE + G::KBUF + p * G::VPL + piece * 1024), 16, 0, 0);
             }
     };
 
     // fragment read address inside a [16 rows][64 B] chunk: row r, logical slot g
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned frag = (unsigned)(r * 64 + ((g ^ ((4 - ((r >> 2) & 3)) & 3)) << 4));
-    const unsigned k_frag = lds0 + frag, v_frag = lds0 + G::KBUF + frag;
+    const unsigned k_frag0 = lds0 + frag, v_frag0 = lds0 + G::KBUF + frag;
 
     f32x4 o[CT];
 #pragma unroll
@@ -169,11 +174,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
     const float alpha = d.alpha;
 
     issue_k(0);
+    if constexpr (G::DBUF) issue_v(0);
     for (int j = 0; j < ntiles; ++j) {
         // ================= phase 1: S^T = K_j Q^T, online softmax =================
         wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();              // K_j visible; every wave has finished reading V^T_{j-1}
-        issue_v(j);
+        __builtin_amdgcn_s_barrier();              // K_j (and V^T_j) visible; every wave has finished tile j - 1
+        unsigned k_frag = k_frag0, v_frag = v_frag0;
+        if constexpr (G::DBUF) {
+            k_frag += (j & 1) * G::TILE;
+            v_frag += (j & 1) * G::TILE;
+            if (j + 1 < ntiles) {
+                issue_k(j + 1, (j + 1) & 1);
+                issue_v(j + 1, (j + 1) & 1);
+            }
+        } else {
+            issue_v(j);
+        }
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
         {
             // bf16 mode: fragments of step ks + 1 are fetched under the MFMAs of step ks; bf16x3 mode has no registers to
@@ -248,9 +264,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
             }
         }
         // ================= phase 2: O^T += V^T_j P^T =================
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();              // V^T_j visible; every wave has finished reading K_j
-        if (j + 1 < ntiles) issue_k(j + 1);
+        if constexpr (!G::DBUF) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // V^T_j visible; every wave has finished reading K_j
+            if (j + 1 < ntiles) issue_k(j + 1);
+        }
         {
             constexpr int NB = NS == 1 ? 2 : 1;
             bf16x8 vf[NB][NS];
@@ -330,7 +348,8 @@ int flash_dispatch(const FridoAttnSmall& d, hipStream_t s) {
     // 8 waves (128 queries) per workgroup halve the L2 -> LDS bytes per FLOP; 4 waves when that would leave CUs idle or the
     // accumulators do not fit 256 registers
     if constexpr (D <= 384) {
-        if ((int64_t)d.B * ((d.Nq + 127) / 128) >= 200) return flash_launch<D, 1, 8, 1>(d, s);
+        static const int min_wgs = getenv("FRIDO_FLASH_NW8_MIN_WGS") ? atoi(getenv("FRIDO_FLASH_NW8_MIN_WGS")) : 200;
+        if ((int64_t)d.B * ((d.Nq + 127) / 128) >= min_wgs) return flash_launch<D, 1, 8, 1>(d, s);
     }
     return flash_launch<D, 1, 4, 1>(d, s);
 }

@@ -181,12 +181,13 @@ class POperand:
 class Prog:
     """A list of ops + the tensors they reference (kept alive)."""
 
-    def __init__(self, device, nsplit):
+    def __init__(self, device, nsplit, ws_tag=""):
         self.device, self.nsplit = device, nsplit
         self.ops = []
         self.keep = []
         self._packed = None
         self.flops = 0
+        self.ws_tag = ws_tag          # split-K workspace identity (programs that may run concurrently must not share one)
 
     # ---- emission helpers -------------------------------------------------------------------
     def emit(self, kind, **kw):
@@ -229,7 +230,7 @@ class Prog:
             st = self.ops[-1][1]
             st.tile, st.splitk = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
             if st.splitk > 1:
-                st.ws = tune.workspace(self.device, _lib.lib().frido_gemm_workspace_bytes(C.addressof(st)))
+                st.ws = tune.workspace(self.device, _lib.lib().frido_gemm_workspace_bytes(C.addressof(st)), self.ws_tag)
         self.flops += 2 * M * N * (K + K2) * batch * (3 if self.nsplit == 2 else 1)
 
     # ---- execution ---------------------------------------------------------------------------

@@ -21,6 +21,26 @@ def _weights_of(module, device):
     return {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in module.state_dict().items()}
 
 
+def _timing_filter(ops):
+    """FRIDO_DEBUG_SKIP=KIND[,KIND...] (e.g. GN_APPLY,LAYERNORM, or GEMM:conv / GEMM:dense) drops those ops from the captured
+    step body.  TIMING EXPERIMENTS ONLY (the results are garbage): it measures what a bucket of launches costs inside the
+    replayed graph, which per-op event timing overstates (tools/ab_flags.sh FRIDO_DEBUG_SKIP "" GN_APPLY ...)."""
+    import os
+    skip = [k for k in os.environ.get("FRIDO_DEBUG_SKIP", "").split(",") if k]
+    if not skip:
+        return ops
+    names = {v: k[len("FRIDO_OP_"):] for k, v in _lib.OP_KINDS.items()}
+    out = []
+    for kind, st in ops:
+        n = names[kind]
+        tags = {n}
+        if n == "GEMM":
+            tags.add("GEMM:conv" if st.conv else "GEMM:dense")
+        if not tags & set(skip):
+            out.append((kind, st))
+    return out
+
+
 def _run1(builder, kind, stream, **kw):
     """Launch a single op immediately."""
     from .engine import Prog
@@ -36,6 +56,15 @@ class DenoiserRuntime:
         self.nsplit = config.nsplit(precision)
         self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
         self.plans = {}
+        self._replicas = {0: self.b}
+
+    def builder_for(self, replica):
+        """Builder of sampler replica `replica`.  Replica 0 is the runtime's own; further replicas get their OWN activation
+        pool, persistent buffers and split-K workspace (they share the f32 weight tensors, not the scratch), so that their
+        captured step bodies can be replayed CONCURRENTLY on different streams (pipeline.sample_images substreams)."""
+        if replica not in self._replicas:
+            self._replicas[replica] = Builder(self.device, self.nsplit, self.b.w, ws_tag=f":r{replica}")
+        return self._replicas[replica]
 
     def forward(self, x, t, context, stage):
         """x (B, Cin, H, W) f32 cuda NCHW, t (B,) int64, context (B, nctx, cd) -> eps (B, nch, H, W)."""
@@ -246,7 +275,7 @@ class SamplerEngine:
             key = ("ddim", s)
             if key not in self.graphs:
                 full = Prog(self.dev, self.b.nsplit)
-                full.ops = list(plan.step.ops)
+                full.ops = _timing_filter(list(plan.step.ops))
                 full.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0))
                 full.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
                 full.keep = [plan]

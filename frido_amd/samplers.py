@@ -40,19 +40,19 @@ class _SamplerBase:
         self.ddim_sqrt_one_minus_alphas = np.sqrt((np.float32(1.0) - al).astype(np.float32))
         self.alphas_cumprod = ac
 
-    def _engine(self, B, shape, nctx, S, eta, scale, num_stage, temperature):
+    def _engine(self, B, shape, nctx, S, eta, scale, num_stage, temperature, replica=0):
         from .runtime import SamplerEngine
         unet = self.model.model.diffusion_model
         rt = unet.runtime()
         C, H, W = shape
-        key = (self.KIND, B, C, H, W, nctx, S, float(eta), scale != 1.0, num_stage, float(temperature))
+        key = (self.KIND, B, C, H, W, nctx, S, float(eta), scale != 1.0, num_stage, float(temperature), replica)
         cache = rt.__dict__.setdefault("_sampler_engines", collections.OrderedDict())
         if key in cache:
             cache.move_to_end(key)
         else:
             while len(cache) >= ENGINE_CACHE_SIZE:      # least-recently-used engine goes (frees its HBM)
                 cache.popitem(last=False)
-            cache[key] = SamplerEngine(rt.b, unet.cfg, B=B, C=C, H=H, W=W, nctx=nctx, S=S, eta=eta, kind=self.KIND,
+            cache[key] = SamplerEngine(rt.builder_for(replica), unet.cfg, B=B, C=C, H=H, W=W, nctx=nctx, S=S, eta=eta, kind=self.KIND,
                                        alphas_cumprod=self.model.alphas_cumprod.detach().float().cpu().numpy(),
                                        embed_dim=self.model.embed_dim_list, cfg_scale=scale, num_stage=num_stage,
                                        temperature=temperature)
@@ -65,7 +65,7 @@ class _SamplerBase:
                img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
                score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1., unconditional_conditioning=None, noise="torch", seed=0, sample0=0,
-               **kwargs):
+               replica=0, **kwargs):
         if mask is not None or x0 is not None or score_corrector is not None or quantize_x0 or noise_dropout > 0.:
             raise NotImplementedError("mask / x0 / score_corrector / quantize_x0 / noise_dropout are not on the HIP path "
                                       "(no shipped Frido sampling script uses them; quantize_x0 exit()s in the reference)")
@@ -84,7 +84,7 @@ class _SamplerBase:
         if unconditional_guidance_scale != 1.:
             assert unconditional_conditioning is not None
         eng = self._engine(batch_size, tuple(shape), conditioning.shape[1], S, eta, unconditional_guidance_scale, num_stage,
-                           temperature)
+                           temperature, replica)
         if verbose:
             print(f"Data shape for {self.KIND.upper()} sampling is {(batch_size, *shape)}, eta {eta}")
         self.num_stage = num_stage

@@ -70,9 +70,10 @@ def _buf(name, nbytes, device):
 _ws = {}
 
 
-def workspace(device, nbytes):
-    """Process-wide split-K workspace (ops of all programs run in stream order, so one buffer is enough)."""
-    key = str(device)
+def workspace(device, nbytes, tag=""):
+    """Split-K workspace: one per (device, tag).  Ops of all programs of one builder run in stream order, so they share one
+    buffer; builders whose programs run CONCURRENTLY on different streams pass their own tag."""
+    key = str(device) + tag
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         old = t

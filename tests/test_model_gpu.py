@@ -596,3 +596,24 @@ def test_config5_three_scale_512_forward_and_decode():
     print(f"config5 decode: VQ flips {flips:.2e}, decoder rel err on the reference's codes {r:.2e}")
     assert dec.shape == (1, 3, 512, 512) and flips < 1e-3 and r < 3e-4
     assert abs(float(forced.double().sum()) - float(gv["dec_img_sum"])) < 2e-4 * float(gv["dec_img_abs_sum"])
+
+
+def test_bench_under_torchrun_takes_the_rccl_path_at_n1():
+    """The driver launches bench.py with torch.distributed.run for N > 1; at N = 1 the same launch exercises the whole
+    distributed path on one GPU: nccl (= RCCL) process group, contiguous shard with sample0, the all-gather of decoded
+    images, the barrier-bracketed max-over-ranks timing and the per-rank report."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "1",
+                          "--warmup", "0", "--batch", "2", "--ddim-steps", "4", "--no-cpu-baseline", "--no-parity-mode"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=repo)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and len(d["per_rank_ms_per_step"]) == 1
+    assert d["config"]["global_batch"] == 2 and "roofline" in d
