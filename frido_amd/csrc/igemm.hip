@@ -75,6 +75,31 @@ __device__ __forceinline__ void wait_tail(int rem) {
     }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_write32(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ float4 lds_read128f(unsigned addr) {
+    float4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint4 lds_read128u(unsigned addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
 // ---- epilogue (shared by the ring kernel and the patch-staged 3x3 kernel) --------------------------------------
 template <int BM, int BN, int NS, int WM, bool RSTAGE>
 __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[BM / WM / 16][BN / 2 / 16], unsigned char* smem,
@@ -87,7 +112,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
     // as 16-byte stores (store ISSUE, not bandwidth, bounds this phase: 8-byte stores measured 2x slower).
     constexpr int WR = BM / WM, WC = BN / WN, EPS = WC + 4;          // +4 floats: conflict-free slab writes
     constexpr int LPR8 = WC / 8, RPP8 = 64 / LPR8;                    // lanes per row (8 columns each), rows per pass
-    if (d.act == 99) {      // profiling aid (tools/gemm_bench.py NOEPI=1): keep the accumulators live, store nothing
+    if (d.act == 99 || (d.flags & 4)) {      // profiling aid (flags bit 2: the same inside a captured graph) (tools/gemm_bench.py NOEPI=1): keep the accumulators live, store nothing
         float sink = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -169,6 +194,70 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             const int n = nbase + jo * 32 + col_l;
             gba[jo] = d.bias && n + 16 < d.N ? d.bias[n] : 0.f;
             gbg[jo] = d.bias && n + 16 < d.N ? d.bias[n + 16] : 0.f;
+        }
+    }
+    // ---- streamlined path: bf16 output (stream or operand), bias (+ hoisted timestep vector) (+ staged bf16 residual), no
+    //      activation / alpha / row bias.  This is every 3x3 conv and most GEMMs of the bf16 sampler.  r02: inside the replayed
+    //      graph the general slab loop below cost 0.86 ms of a 7.5 ms forward WITHOUT its stores (profiles/
+    //      r02_epilogue_in_graph.txt): hipcc fences every C++ LDS read of a kernel that also issues LDS-DMA with
+    //      s_waitcnt vmcnt(0), and on CDNA4 vmcnt counts STORES too -- each pass waited for the previous pass's global
+    //      store -- and the descriptor's run-time switches were ~40 scalar branches per pass.  Here every LDS access is
+    //      inline asm (counted by hand with one lgkmcnt(0) per slab), the four passes of a slab are unrolled (their reads
+    //      issue back to back) and the slabs are unrolled (static accumulator indices, no copies).
+    if constexpr (NS == 1) {
+        const bool one_out = (d.out_f32 && d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
+        const bool simple = fast && !wsp && !d.geglu && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) &&
+                            (!d.residual || res_stage) && !up2 && d.alpha == 1.0f && one_out && !(d.flags & 16);
+        if (simple) {
+            if (res_stage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's residual sub-tile has landed
+            frido_bf16* obase = d.out_f32 ? reinterpret_cast<frido_bf16*>(d.out_f32) + of_base : d.out_op + oo_base;
+            const int64_t ldout = d.out_f32 ? d.ldo : d.ldoo;
+            const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+            const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;       // slab write address of this lane
+            const unsigned ra = lds0 + (unsigned)((wave * 16 + er8) * EPS + ec8) * 4u;          // read-back address (pass 0)
+            const unsigned rsa = (unsigned)(size_t)(lptr_t)rstage + (unsigned)(er8 * LPR8 + (ec8 >> 3)) * 16u;
+            const bool col_ok = lane_on8 && ncol < d.N;
+            const bool has_res = res_stage;
+            static_for<0, TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    lds_write32<(0 * EPS + j * 16) * 4>(wa, acc[i][j][0]);
+                    lds_write32<(1 * EPS + j * 16) * 4>(wa, acc[i][j][1]);
+                    lds_write32<(2 * EPS + j * 16) * 4>(wa, acc[i][j][2]);
+                    lds_write32<(3 * EPS + j * 16) * 4>(wa, acc[i][j][3]);
+                });
+                float4 lo[NP], hi[NP];
+                uint4 rs[NP];
+                static_for<0, NP>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    lo[pp] = lds_read128f<pp * RPP8 * EPS * 4>(ra);
+                    hi[pp] = lds_read128f<pp * RPP8 * EPS * 4 + 16>(ra);
+                    if (has_res) rs[pp] = lds_read128u<(i * 16 + pp * RPP8) * LPR8 * 16>(rsa);
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NP>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    const int r = pp * RPP8 + er8;
+                    const int m = m0 + wm * WR + i * 16 + r;
+                    if (col_ok && r < 16 && m < d.M) {
+                        float v[8] = {lo[pp].x + bia[0], lo[pp].y + bia[1], lo[pp].z + bia[2], lo[pp].w + bia[3],
+                                      hi[pp].x + bia[4], hi[pp].y + bia[5], hi[pp].z + bia[6], hi[pp].w + bia[7]};
+                        if (has_res) {
+                            const uint4 u = rs[pp];
+                            v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                            v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                            v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                            v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint4*>(obase + (int64_t)m * ldout + ncol) =
+                            make_uint4(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16),
+                                       f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16), f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16));
+                    }
+                });
+            });
+            return;
         }
     }
     for (int i = 0; i < TM; ++i) {
@@ -291,7 +380,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                     v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
                 }
             }
-            if (d.act == 98) { if (v[0] == 1.2345e-30f) d.out_f32[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; continue; }
+            if (d.act == 98 || (d.flags & 8)) { if (v[0] == 1.2345e-30f) d.out_f32[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; continue; }
             if (d.out_f32) {
                 const int64_t o = of_base + out_row(m) * d.ldo + n;
                 if (d.out_bf16) {
@@ -576,13 +665,6 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 //   k-walk: for every 32-channel chunk: 9 taps; then the chunks of the optional second operand A2 (fused 1x1 skip conv,
 //   centre tap only).  vmcnt: loads retire in order, so "stage landed" = at most (pieces issued after it) outstanding; the
 //   per-wave issue counter and the marks of the DB-1 youngest weight stages / two patches live in SGPRs.
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // NW = 8: 256 x 192 tile (one workgroup per CU);  NW = 4: 128 x 192 tile (two per CU) for the planes where 256-row tiles
 // would leave CUs idle.  Both: wave tile 64 x 96, 12 weight chunks of 1 KiB per tap dealt round-robin to the waves.

@@ -92,7 +92,9 @@ typedef struct FridoGemm {
                                    7 = 256x128, 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64) */
     int32_t flags;              /* A/B switches (0 = defaults): bit 0 = do not stage the bf16 residual tile through LDS in the
-                                   epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias */
+                                   epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
+                                   streamlined bf16 epilogue; TIMING EXPERIMENTS ONLY
+                                   (results are garbage): bit 2 = skip the whole epilogue, bit 3 = skip only its stores */
 } FridoGemm;
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two
