@@ -28,6 +28,13 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     return u >> 16;
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+// two fp32 -> one packed bf16 pair {lo, hi}, round-to-nearest-even, as ONE v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 // split v into hi (bf16) and lo (bf16 of the residual): v ~= hi + lo to ~2^-17 relative
 __device__ __forceinline__ void split_bf16(float v, uint32_t& hi, uint32_t& lo) {

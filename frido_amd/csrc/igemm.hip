@@ -252,8 +252,85 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                             v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
                         }
                         *reinterpret_cast<uint4*>(obase + (int64_t)m * ldout + ncol) =
-                            make_uint4(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16),
-                                       f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16), f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16));
+                            make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    }
+                });
+            });
+            return;
+        }
+    }
+    // ---- the same treatment for the two other hot forms: split-K partial sums (raw f32 slabs to the workspace) and the fused
+    //      GEGLU projection (a * gelu(gate) formed in registers, operand output)
+    if (fast && wsp && !(d.flags & 48)) {
+        const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+        const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;
+        const unsigned ra = lds0 + (unsigned)((wave * 16 + er8) * EPS + ec8) * 4u;
+        const bool col_ok = lane_on8 && ncol < d.N;
+        static_for<0, TM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                lds_write32<(0 * EPS + j * 16) * 4>(wa, acc[i][j][0]);
+                lds_write32<(1 * EPS + j * 16) * 4>(wa, acc[i][j][1]);
+                lds_write32<(2 * EPS + j * 16) * 4>(wa, acc[i][j][2]);
+                lds_write32<(3 * EPS + j * 16) * 4>(wa, acc[i][j][3]);
+            });
+            float4 lo[NP], hi[NP];
+            static_for<0, NP>([&](auto pc) {
+                constexpr int pp = decltype(pc)::value;
+                lo[pp] = lds_read128f<pp * RPP8 * EPS * 4>(ra);
+                hi[pp] = lds_read128f<pp * RPP8 * EPS * 4 + 16>(ra);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NP>([&](auto pc) {
+                constexpr int pp = decltype(pc)::value;
+                const int r = pp * RPP8 + er8;
+                const int m = m0 + wm * WR + i * 16 + r;
+                if (col_ok && r < 16 && m < d.M) {
+                    float* w = wsp + (int64_t)m * d.N + ncol;
+                    *reinterpret_cast<float4*>(w) = lo[pp];
+                    *reinterpret_cast<float4*>(w + 4) = hi[pp];
+                }
+            });
+        });
+        return;
+    }
+    if constexpr (NS == 1 && (TN % 2) == 0) {
+        if (d.geglu && d.out_op && d.alpha == 1.0f && !(d.flags & 80)) {
+            constexpr int OC = WC / 2, LPRG = OC / 8, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16, NPG = (16 + RPPG - 1) / RPPG;
+            const int gr = lane / LPRG, oc = (lane - gr * LPRG) * 8;          // row, first output column of this lane
+            const int no = (nbase >> 1) + oc;
+            const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+            const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;
+            const unsigned ra = lds0 + (unsigned)((wave * 16 + gr) * EPS + oc) * 4u;
+            const bool col_ok = lane < RPPG * LPRG && no + 7 < (d.N >> 1);
+            static_for<0, TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, TN / 2>([&](auto jc) {
+                    constexpr int jo = decltype(jc)::value;
+                    lds_write32<(0 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][0] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][0] + gbg[jo]));
+                    lds_write32<(1 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][1] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][1] + gbg[jo]));
+                    lds_write32<(2 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][2] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][2] + gbg[jo]));
+                    lds_write32<(3 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][3] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][3] + gbg[jo]));
+                });
+                float4 lo[NPG], hi[NPG];
+                static_for<0, NPG>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    lo[pp] = lds_read128f<pp * RPPG * EPS * 4>(ra);
+                    hi[pp] = lds_read128f<pp * RPPG * EPS * 4 + 16>(ra);
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NPG>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    const int r = pp * RPPG + gr;
+                    const int m = m0 + wm * WR + i * 16 + r;
+                    if (col_ok && r < 16 && m < d.M) {
+                        const float4 a = lo[pp], b = hi[pp];
+                        *reinterpret_cast<uint4*>(d.out_op + (int64_t)m * d.ldoo + no) =
+                            make_uint4(f32_to_bf16_bits(a.x) | (f32_to_bf16_bits(a.y) << 16), f32_to_bf16_bits(a.z) | (f32_to_bf16_bits(a.w) << 16),
+                                       f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16), f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16));
                     }
                 });
             });

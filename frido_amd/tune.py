@@ -23,6 +23,8 @@ _dirty = False
 
 
 def _lib_tag():
+    if os.environ.get("FRIDO_TUNE_TAG"):      # A/B of two library builds with the SAME pinned tiles (tools/ab_lib.sh)
+        return os.environ["FRIDO_TUNE_TAG"]
     try:
         return str(os.path.getsize(_lib.LIB_PATH))
     except OSError:

@@ -93,7 +93,7 @@ typedef struct FridoGemm {
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64) */
     int32_t flags;              /* A/B switches (0 = defaults): bit 0 = do not stage the bf16 residual tile through LDS in the
                                    epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
-                                   streamlined bf16 epilogue; TIMING EXPERIMENTS ONLY
+                                   streamlined epilogues (bit 5 / 6: only the split-K / GEGLU one); TIMING EXPERIMENTS ONLY
                                    (results are garbage): bit 2 = skip the whole epilogue, bit 3 = skip only its stores */
 } FridoGemm;
 

@@ -1,11 +1,13 @@
 #!/bin/bash
-# A/B two builds of the library on the full benchmark, interleaved on ONE box, each with its own pinned tile cache:
+# A/B two builds of the library on the full benchmark, interleaved on ONE box, with the SAME pinned tile choices (tuned once
+# with the first library; a tile one build lacks falls back to the static heuristic):
 #   tools/ab_lib.sh frido_amd/libfrido_hip_old.so frido_amd/libfrido_hip.so
 A=${1:?old lib}; B=${2:?new lib}
-for L in $A $B; do FRIDO_LIB=$PWD/$L FRIDO_TUNE_CACHE=/tmp/tune_$(basename $L).json python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1; done
+export FRIDO_TUNE_TAG=ab FRIDO_TUNE_CACHE=/tmp/tune_ab.json
+FRIDO_LIB=$PWD/$A python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
 for i in 1 2 3; do
   for L in $A $B; do
-    FRIDO_LIB=$PWD/$L FRIDO_TUNE_CACHE=/tmp/tune_$(basename $L).json python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode 2>&1 | grep -v amdgpu.ids | tail -1 |
+    FRIDO_LIB=$PWD/$L python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode 2>&1 | grep -v amdgpu.ids | tail -1 |
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$L', d['value'], 'images/s', d['ms_per_step'], 'ms/batch')"
   done
 done
