@@ -387,6 +387,16 @@ def gen_vq_512():
     save("vq_512", **out)
 
 
+def gen_vq_full_enc():
+    """SURVEY a16 at full width: VQModelInterface.encode (msvqgan.py:326-374: MSEncoder, coarse-to-fine with VQ + ConvTranspose +
+    shared decoder) of one 256 x 256 image with the layout2i f8f4 first stage."""
+    net = build_vq(VQ_FULL)
+    x = T(np.tanh(seeded_normal("vq_full:img", (1, 3, 256, 256))))
+    with torch.no_grad():
+        enc = net.encode(x)
+    save("vq_full_enc", enc=enc.numpy())          # the image is regenerated from its seed by the tests
+
+
 def gen_sampler_xt():
     """The x_T quirk (ddim.py:150-152, plms.py:150-152): a supplied x_T is taken as the FINISHED stage-0 result -- stage 0
     and its pooling hand-off are skipped."""
@@ -419,6 +429,7 @@ GENS = {
     "sampler_small": lambda: gen_sampler("sampler_small", UNET_SMALL, VQ_SMALL, BERT_SMALL, B=2, nctx=5),
     "sampler_small3": lambda: gen_sampler("sampler_small3", UNET_SMALL3, VQ_SMALL3, BERT_SMALL, B=1, nctx=7),
     "sampler_xt": gen_sampler_xt,
+    "vq_full_enc": gen_vq_full_enc,
     "sampler_full": gen_sampler_full,
     "sampler_t2i": gen_sampler_t2i,
     "unet_512": gen_unet_512,

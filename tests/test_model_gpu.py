@@ -227,6 +227,13 @@ def test_full_pipeline_with_cond_stage_and_get_input():
     z, cc, x, xrec = m.get_input(batch, "image", return_first_stage_outputs=True, force_c_encode=True)
     assert z.shape == (2, 6, 16, 16) and cc.shape == c.shape and xrec.shape == (2, 3, 64, 64)
     assert _rel(cc, g["c"]) < 1e-4
+    # z = encode_first_stage(x) with the per-scale scale_factor applied (frido.py:647-662,767-816) vs the oracle
+    from oracle.vqgan import vq_encode
+    zr = vq_encode(synth_sd(vq_holder(VQ_SMALL), "first_stage_model."), VQ_SMALL, batch["image"].permute(0, 3, 1, 2).contiguous())
+    zr[:, :3] *= 0.9
+    zr[:, 3:] *= 1.1
+    zerr = (z.cpu() - zr).abs()
+    assert float(zerr[:, :3].max()) < 5e-4 * float(zr.abs().max()) and float((zerr > 5e-4 * float(zr.abs().max())).float().mean()) < 0.02
     tape = _Tape(g["ddim_eta1_noise"])
     with m.ema_scope():
         pass
@@ -617,3 +624,47 @@ def test_bench_under_torchrun_takes_the_rccl_path_at_n1():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and len(d["per_rank_ms_per_step"]) == 1
     assert d["config"]["global_batch"] == 2 and "roofline" in d
+
+
+def test_vq_full_width_encode_matches_reference_golden():
+    """SURVEY a16 at full width (layout2i f8f4 first stage, one 256 x 256 image) vs the reference's own encode."""
+    from frido_amd.synth import seeded_normal
+    g = golden("vq_full_enc")
+    m = _vq(VQ_FULL)
+    x = torch.from_numpy(np.tanh(seeded_normal("vq_full:img", (1, 3, 256, 256))))
+    enc = m.encode(x.cuda())
+    ref = torch.from_numpy(g["enc"])
+    err = (enc.cpu() - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"vq_full encode: coarse max err {float(err[:, :3].max()) / scale:.2e} rel, fine-scale pixels off by > 5e-4 rel: {100 * float((err[:, 3:] > 5e-4 * scale).float().mean()):.3f} %")
+    assert enc.shape == ref.shape and float(err[:, :3].max()) < 5e-4 * scale          # no VQ in the coarse path
+    assert float((err > 5e-4 * scale).float().mean()) < 0.02                          # a coarse code flip perturbs few fine pixels
+
+
+def test_sampling_inside_ema_scope_uses_the_ema_weights():
+    """frido.py:181-194 / ema.py:46-76 with DISTINCT EMA weights: inside the scope the sampler runs on the shadow weights
+    (checked against the oracle with those weights), afterwards on the training weights again."""
+    from frido.models.diffusion.ddim import DDIMSampler
+    from frido_amd.synth import fill_tensor, seeded_normal
+    from oracle import samplers as S
+    from oracle.unet import unet_forward
+    model = _frido(UNET_SMALL, VQ_SMALL)
+    # shadow weights = the filler under a different name prefix
+    for name, p in model.model.named_parameters():
+        getattr(model.model_ema, model.model_ema.m_name2s_name[name]).copy_(torch.from_numpy(fill_tensor("ema." + name, p.shape)))
+    sd_train = synth_sd(unet_holder(UNET_SMALL), "model.diffusion_model.")
+    sd_ema = {"model.diffusion_model." + k: torch.from_numpy(fill_tensor("ema.diffusion_model." + k, v.shape))
+              for k, v in unet_holder(UNET_SMALL).state_dict().items()}
+    c = torch.from_numpy(seeded_normal("ema:c", (2, 5, 64)))
+    tape = seeded_normal("ema:noise", (2 * 6 * 256 + 4 * 2 * 3 * 256 + 4 * 2 * 6 * 256,))
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    kw = dict(S=4, batch_size=2, shape=(6, 16, 16), conditioning=c.cuda(), num_stage=2, eta=1.0, verbose=False)
+
+    def ref(sd):
+        return S.ddim_sample(lambda x, t, cc, s: unet_forward(sd, UNET_SMALL, x, t, cc, s), ac, 4, (2, 6, 16, 16), c, [3, 3], [3, 3], 2,
+                             eta=1.0, noise=S.NoiseSource(tape))[0]
+    with model.ema_scope("test"):
+        z_ema, _ = DDIMSampler(model).sample(noise=_Tape(tape), **kw)
+    z_train, _ = DDIMSampler(model).sample(noise=_Tape(tape), **kw)
+    assert _rel(z_ema, ref(sd_ema)) < 1e-3 and _rel(z_train, ref(sd_train)) < 1e-3
+    assert _rel(z_ema, z_train.cpu()) > 1e-2            # the two weight sets really differ

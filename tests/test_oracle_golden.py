@@ -214,3 +214,15 @@ def test_full_width_ddim4_oracle():
     assert float((out - torch.from_numpy(g["ddim4_samples"])).abs().max()) < 2e-5
     img = S.decode_first_stage(lambda z: vq_decode(vsd, VQ_FULL, z), torch.from_numpy(g["ddim4_samples"]), g["scale_factor"].tolist(), [3, 3])
     _check_img(img, g, "ddim4", 2e-5)
+
+
+@pytest.mark.slow
+def test_vq_full_width_encode_oracle():
+    """SURVEY a16 at full width: the oracle's encode vs the reference's (coarse channels exact to rounding; the fine scale
+    passes through a VQ of the coarse one, so a single code flip would show up as an outlier -- there is none on CPU)."""
+    from frido_amd.synth import seeded_normal
+    g = golden("vq_full_enc")
+    sd = synth_sd(vq_holder(VQ_FULL), "first_stage_model.")
+    x = torch.from_numpy(np.tanh(seeded_normal("vq_full:img", (1, 3, 256, 256))))
+    enc = vq_encode(sd, VQ_FULL, x)
+    assert enc.shape == g["enc"].shape and float((enc - torch.from_numpy(g["enc"])).abs().max()) < 2e-5
