@@ -207,7 +207,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
     if constexpr (NS == 1) {
         const bool one_out = (d.out_f32 && d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
         const bool simple = fast && !wsp && !d.geglu && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) &&
-                            (!d.residual || res_stage) && !up2 && d.alpha == 1.0f && one_out && !(d.flags & 16);
+                            (!d.residual || res_stage) && d.alpha == 1.0f && one_out && !(d.flags & 16);
         if (simple) {
             if (res_stage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's residual sub-tile has landed
             frido_bf16* obase = d.out_f32 ? reinterpret_cast<frido_bf16*>(d.out_f32) + of_base : d.out_op + oo_base;
@@ -251,8 +251,82 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                             v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
                             v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
                         }
-                        *reinterpret_cast<uint4*>(obase + (int64_t)m * ldout + ncol) =
+                        *reinterpret_cast<uint4*>(obase + out_row(m) * ldout + ncol) =      // out_row: upsample phase interleave
                             make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    }
+                });
+            });
+            return;
+        }
+    }
+    // ---- bf16x3 (parity) mode: f32 stream or hi/lo operand output, bias (+ hoisted timestep vector), optional f32 residual whose
+    //      rows are fetched at the top of their slab (one load round trip per slab instead of one per pass)
+    if constexpr (NS == 2) {
+        const bool one_out = (d.out_f32 && !d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
+        const bool simple2 = fast && !wsp && !d.geglu && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) &&
+                             !(d.residual && d.res_bf16) && !up2 && d.alpha == 1.0f && one_out && !(d.flags & 16);
+        if (simple2) {
+            const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+            const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;
+            const unsigned ra = lds0 + (unsigned)((wave * 16 + er8) * EPS + ec8) * 4u;
+            const bool col_ok = lane_on8 && ncol < d.N;
+            const bool has_res = d.residual != nullptr;
+            const float* rbase = reinterpret_cast<const float*>(d.residual) + rs_base + ncol;
+            static_for<0, TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float4 r0[NP], r1[NP];
+                if (has_res) {
+                    static_for<0, NP>([&](auto pc) {
+                        constexpr int pp = decltype(pc)::value;
+                        const int r = pp * RPP8 + er8;
+                        int m = m0 + wm * WR + i * 16 + r;
+                        m = m < d.M ? m : d.M - 1;
+                        r0[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        r1[pp] = r0[pp];
+                        if (col_ok) {
+                            r0[pp] = *reinterpret_cast<const float4*>(rbase + (int64_t)m * d.ldr);
+                            r1[pp] = *reinterpret_cast<const float4*>(rbase + (int64_t)m * d.ldr + 4);
+                        }
+                    });
+                }
+                static_for<0, TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    lds_write32<(0 * EPS + j * 16) * 4>(wa, acc[i][j][0]);
+                    lds_write32<(1 * EPS + j * 16) * 4>(wa, acc[i][j][1]);
+                    lds_write32<(2 * EPS + j * 16) * 4>(wa, acc[i][j][2]);
+                    lds_write32<(3 * EPS + j * 16) * 4>(wa, acc[i][j][3]);
+                });
+                float4 lo[NP], hi[NP];
+                static_for<0, NP>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    lo[pp] = lds_read128f<pp * RPP8 * EPS * 4>(ra);
+                    hi[pp] = lds_read128f<pp * RPP8 * EPS * 4 + 16>(ra);
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NP>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    const int r = pp * RPP8 + er8;
+                    const int m = m0 + wm * WR + i * 16 + r;
+                    if (col_ok && r < 16 && m < d.M) {
+                        float v[8] = {lo[pp].x + bia[0], lo[pp].y + bia[1], lo[pp].z + bia[2], lo[pp].w + bia[3],
+                                      hi[pp].x + bia[4], hi[pp].y + bia[5], hi[pp].z + bia[6], hi[pp].w + bia[7]};
+                        if (has_res) {
+                            v[0] += r0[pp].x; v[1] += r0[pp].y; v[2] += r0[pp].z; v[3] += r0[pp].w;
+                            v[4] += r1[pp].x; v[5] += r1[pp].y; v[6] += r1[pp].z; v[7] += r1[pp].w;
+                        }
+                        if (d.out_f32) {
+                            float* o = d.out_f32 + of_base + (int64_t)m * d.ldo + ncol;
+                            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else {
+                            uint32_t h[8], l[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+                            frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + ncol;
+                            *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                            *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+                        }
                     }
                 });
             });
