@@ -18,6 +18,8 @@ TILES8W = (7, 8)                    # 8-wave 256-row tiles (bf16 mode)
 _cache = {}
 _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
+K64_ALL = os.environ.get("FRIDO_TUNE_K64_ALL", "0") != "0"           # try the BK = 64 tiles on every shape, not only small M
+BIG_SPLITK = os.environ.get("FRIDO_TUNE_BIG_SPLITK", "1") != "0"      # also try the 8-wave 256-row tiles under split-K
 CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
 _dirty = False
 
@@ -142,8 +144,8 @@ def best_tile(st, device, stream):
         t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None
         # BK = 64 halves the barrier count but costs a ring stage of occupancy: it only wins on small-M shapes
         k64 = (st.nsplit == 1 and st.K % 64 == 0 and st.K2 % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
-               and st.M * st.batch <= 4096)
-        big = st.nsplit == 1 and sk == 1 and st.M >= 512 and st.N >= 96
+               and (st.M * st.batch <= 4096 or K64_ALL))
+        big = st.nsplit == 1 and (sk == 1 or BIG_SPLITK) and st.M >= 512 and st.N >= 96
         # tile 9 = patch-staged 3x3 kernel (igemm.hip patch_ok; the library rejects it when it does not apply)
         patch = (st.conv and st.nsplit == 1 and st.batch == 1 and st.kh == 3 and st.stride == 1 and not (st.up_shift or st.dn_shift)
                  and not st.up2_phase and st.M % 128 == 0 and st.M >= 4096 and st.N >= 96 and sk <= (st.Cin + st.K2) // 32)
