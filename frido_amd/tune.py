@@ -18,7 +18,7 @@ TILES8W = (7, 8)                    # 8-wave 256-row tiles (bf16 mode)
 _cache = {}
 _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
-K64_ALL = os.environ.get("FRIDO_TUNE_K64_ALL", "0") != "0"           # try the BK = 64 tiles on every shape, not only small M
+K64_ALL = os.environ.get("FRIDO_TUNE_K64_ALL", "1") != "0"           # try the BK = 64 tiles on every shape, not only small M
 BIG_SPLITK = os.environ.get("FRIDO_TUNE_BIG_SPLITK", "1") != "0"      # also try the 8-wave 256-row tiles under split-K
 CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
 _dirty = False
