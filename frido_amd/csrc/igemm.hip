@@ -1445,6 +1445,7 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
             case 14: return launch<128, 64, NS, CONV, 64>(d, s);
             case 15: return launch<64, 192, NS, CONV, 64>(d, s);
             case 16: return launch<64, 128, NS, CONV, 64>(d, s);
+            case 17: return launch<256, 128, NS, CONV, 64>(d, s);      // 8 waves, 3-deep ring of 48-KiB stages
             default: break;
         }
     }
@@ -1473,7 +1474,7 @@ int frido_igemm_init() {
     FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
-          set_attr<256, 256, 1, false, 32>();
+          set_attr<256, 256, 1, false, 32>() | set_attr<256, 128, 1, true, 64>() | set_attr<256, 128, 1, false, 64>();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             PGeo<192, 8>::SMEM) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -43,7 +43,7 @@ def _t(tag, *shape):
 
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("M,N,K,tile", [(300, 200, 96, 0), (128, 128, 64, 1), (257, 192, 160, 2), (64, 26, 64, 3),
-                                        (1024, 384, 384, 0), (5, 3, 32, 0)])
+                                        (1024, 384, 384, 0), (5, 3, 32, 0), (600, 320, 256, 17), (512, 256, 128, 7)])
 def test_gemm_dense(nsplit, M, N, K, tile):
     a, w, bias, res = _t("ga", M, K), _t("gw", N, K), _t("gb", N), _t("gr", M, N)
     b = _builder(nsplit, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
