@@ -163,12 +163,16 @@ class SamplerEngine:
         return kw
 
     def _upload_noise(self, s, tape):
-        """tape: list of per-step NCHW tensors (B, 3(s+1), H, W) in draw order -> NHWC device buffer."""
+        """tape: list of per-step NCHW tensors (B, 3(s+1), H, W) in draw order -> the stage's persistent NHWC device buffer
+        (fixed address: the captured step body of the tape mode reads it by step index)."""
         Cs = sum(self.embed[:s + 1])
         t = torch.stack([torch.as_tensor(n, dtype=torch.float32) for n in tape])     # [n][B][Cs][H][W]
         assert t.shape[1:] == (self.B, Cs, self.H, self.W), (t.shape, Cs)
-        self.noise_buf = t.permute(0, 1, 3, 4, 2).contiguous().to(self.dev)          # plumbing: layout + H2D
-        return self.noise_buf.data_ptr(), Cs
+        bufs = self.__dict__.setdefault("_tape_bufs", {})
+        if s not in bufs:
+            bufs[s] = torch.empty(t.shape[0], self.B, self.H, self.W, Cs, dtype=torch.float32, device=self.dev)
+        bufs[s].copy_(t.permute(0, 1, 3, 4, 2), non_blocking=False)                 # plumbing: layout + H2D
+        return bufs[s].data_ptr(), Cs
 
     # ---- main entry --------------------------------------------------------------------------------
     @torch.no_grad()
@@ -258,18 +262,24 @@ class SamplerEngine:
             self._last_logged_stage = s if i == n - 1 else None
 
     def _ddim_stage(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs):
-        """ddim.py:155-175.  Philox mode replays ONE captured hipGraph per step (denoiser forward + state update +
-        step-counter bump); tape mode (recorded / torch-CPU noise) runs the same ops eagerly."""
+        """ddim.py:155-175.  ONE captured hipGraph per stage (denoiser forward + state update + step-counter bump) is
+        replayed every step: the Philox form draws its noise in the update kernel, the tape form (recorded / torch-CPU noise)
+        reads the stage's persistent noise buffer by step index."""
         from .engine import Prog
         plan = self.stages[s]
         n = self.n_steps
         if draw is not None:
             noise_ptr, noise_C = self._upload_noise(s, [draw((self.B, Cs, self.H, self.W)) for _ in range(n)])
-            body = Prog(self.dev, self.b.nsplit)
-            body.ops = list(plan.step.ops)
-            body.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=noise_ptr, noise_C=noise_C, seed=0, sample0=0))
-            body.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
-            launch = lambda: body.run(sp)
+            key = ("ddim_tape", s)
+            if key not in self.graphs:
+                body = Prog(self.dev, self.b.nsplit)
+                body.ops = list(plan.step.ops)
+                body.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=noise_ptr, noise_C=noise_C, seed=0, sample0=0))
+                body.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
+                body.keep = [plan]
+                self.graphs[key] = body.capture(sp) if self.use_graph else body
+            g = self.graphs[key]
+            launch = (lambda: g.launch(sp)) if self.use_graph else (lambda: g.run(sp))
         else:
             self.rng.copy_(torch.tensor([seed, sample0], dtype=torch.int64))
             key = ("ddim", s)
