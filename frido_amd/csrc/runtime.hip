@@ -4,7 +4,9 @@
 // VQGAN decode); the Python host builds it once per (model, batch, stage) and replays it.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <mutex>
 #include <vector>
 
@@ -68,15 +70,64 @@ struct Graph {
     hipGraphExec_t exec = nullptr;
 };
 
-}  // namespace
+// side stream + a small ring of ordering events per caller stream (created on first use, never destroyed: a handful per process)
+struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    int next = 0;
+};
+std::mutex g_side_mu;
+std::vector<std::pair<hipStream_t, Side*>> g_sides;
 
-extern "C" int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s) {
-    if (!ops || n < 0) {
-        frido_set_error("frido_run: bad arguments");
-        return FRIDO_EINVAL;
+Side* side_of(hipStream_t main) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (auto& p : g_sides)
+        if (p.first == main) return p.second;
+    Side* sd = new Side();
+    if (hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete sd;
+        return nullptr;
     }
+    for (auto& e : sd->ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_sides.emplace_back(main, sd);
+    return sd;
+}
+
+int run_sync(const FridoSync& d, hipStream_t main, bool serial) {
+    if (serial || d.from == d.to) return FRIDO_OK;       // everything on one stream: already ordered
+    Side* sd = side_of(main);
+    if (!sd) {
+        frido_set_error("frido_run: cannot create the side stream");
+        return FRIDO_EHIP;
+    }
+    hipStream_t from = d.from ? sd->stream : main, to = d.to ? sd->stream : main;
+    hipEvent_t ev = sd->ev[sd->next];
+    sd->next = (sd->next + 1) & 7;
+    if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+        frido_set_error("frido_run: cross-stream ordering failed: %s", hipGetErrorString(hipGetLastError()));
+        return FRIDO_EHIP;
+    }
+    return FRIDO_OK;
+}
+
+int run_prog(const FridoOp* ops, int32_t n, frido_stream_t s, bool serial) {
     for (int32_t i = 0; i < n; ++i) {
-        int rc = run_one(ops[i], s);
+        int rc;
+        if (ops[i].kind == FRIDO_OP_SYNC) {
+            rc = run_sync(ops[i].u.sync, (hipStream_t)s, serial);
+        } else {
+            frido_stream_t st = s;
+            if (ops[i].stream == 1 && !serial) {
+                Side* sd = side_of((hipStream_t)s);
+                if (!sd) {
+                    frido_set_error("frido_run: cannot create the side stream");
+                    return FRIDO_EHIP;
+                }
+                st = (frido_stream_t)sd->stream;
+            }
+            rc = run_one(ops[i], st);
+        }
         if (rc != FRIDO_OK) {
             char tmp[400];
             snprintf(tmp, sizeof(tmp), "%s", g_err);
@@ -85,6 +136,17 @@ extern "C" int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s) {
         }
     }
     return FRIDO_OK;
+}
+
+}  // namespace
+
+extern "C" int frido_run(const FridoOp* ops, int32_t n, frido_stream_t s) {
+    if (!ops || n < 0) {
+        frido_set_error("frido_run: bad arguments");
+        return FRIDO_EINVAL;
+    }
+    static const bool serial = getenv("FRIDO_SERIAL") && atoi(getenv("FRIDO_SERIAL")) != 0;     // A/B: ignore the side stream
+    return run_prog(ops, n, s, serial);
 }
 
 extern "C" int frido_run_timed(const FridoOp* ops, int32_t n, frido_stream_t s, float* ms) {
@@ -98,7 +160,7 @@ extern "C" int frido_run_timed(const FridoOp* ops, int32_t n, frido_stream_t s, 
     int rc = FRIDO_OK;
     (void)hipEventRecord(ev[0], (hipStream_t)s);
     for (int32_t i = 0; i < n && rc == FRIDO_OK; ++i) {
-        rc = run_one(ops[i], s);
+        if (ops[i].kind != FRIDO_OP_SYNC) rc = run_one(ops[i], s);          // per-op timing: everything on the caller's stream
         (void)hipEventRecord(ev[i + 1], (hipStream_t)s);
     }
     if (rc == FRIDO_OK) {
@@ -236,6 +298,7 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_GN_FUSED: return sizeof(FridoGnApply);
         case FRIDO_OP_COPY: return sizeof(FridoCopy);
         case FRIDO_OP_ATTN_FLASH: return sizeof(FridoAttnSmall);
+        case FRIDO_OP_SYNC: return sizeof(FridoSync);
         default: return -1;
     }
 }

@@ -13,7 +13,9 @@ import torch
 
 from . import _lib
 
+import contextlib
 import os
+SIDE_STREAM = os.environ.get("FRIDO_SIDE_STREAM", "0") != "0"   # independent projections of an attention block on a side stream: measured -2.9 % (the fork / join nodes cost more than the overlap buys), off by default
 GEMM_FLAGS = int(os.environ.get("FRIDO_GEMM_FLAGS", "0"))     # FridoGemm.flags A/B switches (include/frido_hip.h)
 BF16X3 = 2   # nsplit: hi + residual plane, 3 MFMAs per product (≈ fp32 accuracy)
 BF16 = 1     # nsplit: plain bf16 operands
@@ -187,12 +189,31 @@ class Prog:
         self.keep = []
         self._packed = None
         self.flops = 0
+        self._sid = 0
         self.ws_tag = ws_tag          # split-K workspace identity (programs that may run concurrently must not share one)
 
     # ---- emission helpers -------------------------------------------------------------------
     def emit(self, kind, **kw):
-        self.ops.append(_lib.make_op(kind, **kw))
+        op = _lib.make_op(kind, **kw)
+        op[1]._sid = self._sid          # stream id of the native executor (0 = caller's stream, 1 = its side stream)
+        self.ops.append(op)
         self._packed = None
+
+    def sync(self, frm, to):
+        """Everything emitted so far for stream `frm` happens before what is emitted later for stream `to`."""
+        if SIDE_STREAM:
+            self.emit("FRIDO_OP_SYNC", **{"from": frm, "to": to})
+
+    @contextlib.contextmanager
+    def side(self):
+        """Ops emitted inside run on the executor's side stream, concurrently with what the caller emits for the main stream
+        between `with` exit and the next sync(1, 0).  The caller brackets the region: sync(0, 1) before, sync(1, 0) after."""
+        prev = self._sid
+        self._sid = 1 if SIDE_STREAM else 0
+        try:
+            yield
+        finally:
+            self._sid = prev
 
     def gemm(self, M, N, K, A, B, *, batch=1, lda=None, ldb=None, a_bs=0, b_bs=0, a_lo=None, b_lo=None,
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,

@@ -226,14 +226,19 @@ class UNetStagePlan:
         n1 = b.layernorm(hcur, t + ".norm1")
         # scores: q' = n1 (W_q^T W_k) against the raw rows of n1 (the key projection is folded into the query side)
         wq, _ = b.folded_qk_weight(t + ".attn1.to_q", t + ".attn1.to_k", "q")
-        qp = b.linear(n1, None, wop=wq, bias=False, out="op")
         Np = rup(HW, 32)
         if (C, HW) not in self._vt_self:
             self._vt_self[(C, HW)] = b.persistent_op(C, Np, batch=Bx, zero=True)
         vT = self._vt_self[(C, HW)]
         # the single-head output projection is folded into V: PV lands directly on the residual stream
         wvo, bvo = b.folded_vo_weight(t + ".attn1.to_v", t + ".attn1.to_out.0")
-        b.v_transposed(n1, C, wvo, Bx, HW, C, out=vT)
+        # the value and query projections both read n1 and are independent: V^T goes to the executor's side stream (a parallel
+        # branch of the captured graph), q' stays on the main one; they join before the attention core
+        b.prog.sync(0, 1)
+        with b.prog.side():
+            b.v_transposed(n1, C, wvo, Bx, HW, C, out=vT)
+        qp = b.linear(n1, None, wop=wq, bias=False, out="op")
+        b.prog.sync(1, 0)
         h2 = b.attention(qp, C, n1, C, vT, Bx, HW, HW, C, bias_ptr=bvo, residual=hcur, stream=True)
         qp.free()
         n1.free()

@@ -56,14 +56,17 @@ def vq_attn(b, B, blk_prefix, C, x, h, w):
     a0, _ = b.groupnorm(x, None, B, HW, pre + ".norm", 1e-6, act=ACT_NONE)
     # scores: q' = a0 (W_q^T W_k) + W_k^T b_q against the raw rows of a0 (key-side bias terms cancel in the softmax)
     wq, bq = b.folded_qk_weight(pre + ".q", pre + ".k", "q")
-    qp = b.linear(a0, None, wop=wq, bias_ptr=bq, bias=False, out="op")
     vkey = ("vT", C, HW, B)
     if vkey not in b._wcache:
         b._wcache[vkey] = b.persistent_op(C, rup(HW, 32), batch=B, zero=True)
     vT = b._wcache[vkey]
     # proj_out folded into v (single head): PV + (W_o b_v + b_o) + x lands directly on the residual stream
     wvo, bvo = b.folded_vo_weight(pre + ".v", pre + ".proj_out")
-    b.v_transposed(a0, C, wvo, B, HW, C, out=vT)
+    b.prog.sync(0, 1)                  # V^T on the side stream, q' on the main one (both read a0), joined before the core
+    with b.prog.side():
+        b.v_transposed(a0, C, wvo, B, HW, C, out=vT)
+    qp = b.linear(a0, None, wop=wq, bias_ptr=bq, bias=False, out="op")
+    b.prog.sync(1, 0)
     out = b.attention(qp, C, a0, C, vT, B, HW, HW, C, bias_ptr=bvo, residual=x, stream=True)
     qp.free()
     a0.free()

@@ -277,20 +277,27 @@ typedef struct FridoCopy { const void* src; void* dst; int64_t n; } FridoCopy;
 /* fill a device buffer with a 32-bit pattern. */
 typedef struct FridoFill { uint32_t* dst; int64_t n; uint32_t value; } FridoFill;
 
+/* Cross-stream ordering inside a program (native executor only): everything enqueued so far on stream `from` happens
+ * before anything enqueued later on stream `to`.  Stream 0 is the caller's stream, stream 1 a side stream the library owns
+ * per caller stream; an op runs on the stream named by FridoOp.stream.  Used to run the two independent projections of an
+ * attention block (frido/modules/attention.py:175-177: to_q / to_v of the same input) concurrently; both directions are
+ * captured into the hipGraph as parallel branches. */
+typedef struct FridoSync { int32_t from, to; } FridoSync;
+
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP_ATTN_FLASH, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP_ATTN_FLASH, FRIDO_OP_SYNC, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
 typedef struct FridoOp {
-    int32_t kind; int32_t _pad;
+    int32_t kind; int32_t stream;   /* 0 = the caller's stream, 1 = the library's side stream (see FridoSync) */
     union {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small; FridoCopy copy;
+        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small; FridoCopy copy; FridoSync sync;
         char _size[384];
     } u;
 } FridoOp;
