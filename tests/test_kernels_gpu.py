@@ -632,3 +632,40 @@ def test_graph_capture_replays():
             g.launch(s.cuda_stream)
     s.synchronize()
     assert int(step.item()) == 10
+
+
+def test_executor_side_stream_branches_join_correctly(monkeypatch):
+    """FRIDO_OP_SYNC + FridoOp.stream: two independent projections of one input on the executor's two streams (eager and as
+    parallel branches of a captured hipGraph), joined before their consumer, give the serial program's result bit for bit."""
+    from frido_amd import engine
+    x, wq, wv = _t("sx", 256, 128), _t("swq", 128, 128) / 11.0, _t("swv", 128, 128) / 11.0
+
+    def build(side):
+        monkeypatch.setattr(engine, "SIDE_STREAM", side)
+        b = _builder(1, {"q.weight": wq.cuda(), "v.weight": wv.cuda()})
+        xd = x.cuda()
+        a = b.pack(xd.data_ptr(), 1, 256, 128, 0, 128)
+        b.prog.sync(0, 1)
+        with b.prog.side():
+            v = b.linear(a, "v", bias=False, out="op")
+        q = b.linear(a, "q", bias=False, out="op")
+        b.prog.sync(1, 0)
+        o = b.linear(v, "q", bias=False, residual=None)          # consumer of the side branch
+        o2 = b.linear(q, "v", bias=False)
+        return b, o, o2, xd
+
+    b0, o0, p0, keep0 = build(False)
+    _run(b0)
+    b1, o1, p1, keep1 = build(True)
+    assert any(getattr(st, "_sid", 0) == 1 for _, st in b1.prog.ops)
+    _run(b1)
+    assert torch.equal(o0.view(), o1.view()) and torch.equal(p0.view(), p1.view())
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = b1.prog.capture(st.cuda_stream)
+        o1.view().zero_()
+        p1.view().zero_()
+        g.launch(st.cuda_stream)
+        g.launch(st.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(o0.view(), o1.view()) and torch.equal(p0.view(), p1.view())
