@@ -101,17 +101,33 @@ __device__ __forceinline__ uint4 lds_read128u(unsigned addr) {
 }
 
 // ---- epilogue (shared by the ring kernel and the patch-staged 3x3 kernel) --------------------------------------
+// Accumulator layout.  The main loops issue every MFMA with the WEIGHT fragment as the first operand and the pixel fragment
+// as the second, so the 16x16 accumulator tile is C^T: lane l holds, for pixel (row of C) l & 15, the FOUR CONSECUTIVE
+// channels 4 * (l >> 4) + e of the tile.  On top of that the weight rows of a tile are dealt to LDS rows PERMUTED
+// (chan_of_pos below, applied to the DMA source address: free): n-tile pair (2J, 2J+1) of a lane covers channels
+// 32 J + 8 (l >> 4) + {0..3 | 4..7}, i.e. EIGHT CONSECUTIVE channels of one pixel = one 16-byte bf16 store.  The hot
+// epilogues therefore go straight from accumulators to global memory: no LDS transposition (r01/r02 spent 3-7 us of a
+// 54 us conv launch writing slabs to LDS and reading them back), no lgkmcnt round trips, one 16-byte store per 8 values,
+// 16 pixel rows x 64 B per wave instruction (store-pattern microbenchmark tools/micro/store_pattern.hip: 6.2 vs 5.5 us per
+// 25 MB for full rows -- the stores cost 0.7 us more, the transposition they replace 3+).
+// GEGLU launches keep the identity row order (value / gate tiles must stay adjacent fragments).
+__device__ __forceinline__ int chan_of_pos(int p) {      // LDS row (position in the tile's B panel) -> channel of the tile
+    return (p & ~31) | ((p & 12) << 1) | ((p & 16) >> 2) | (p & 3);
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_write128(unsigned addr, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
 template <int BM, int BN, int NS, int WM, bool RSTAGE>
 __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[BM / WM / 16][BN / 2 / 16], unsigned char* smem,
                                               int m0, int n0, int wave, int lane, int zo, int zi, int kz) {
-    constexpr int WN = 2, TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int WN = 2, TM = BM / WM / 16, TN = BN / WN / 16, TJ = TN / 2;
+    static_assert(TN % 2 == 0, "n-tile pairs");
     const int wm = wave >> 1, wn = wave & 1;
-    // MFMA leaves lane l with D[row = (l>>4)*4 + e][col = l & 15] of each 16x16 tile (16 lanes x 4 B per row segment).
-    // Each 16-row slab of the wave's sub-tile is transposed through the (now idle) LDS ring so that every lane owns 8
-    // CONSECUTIVE columns of one row: bias / timestep vector / residual come in as 16-byte loads and the results leave
-    // as 16-byte stores (store ISSUE, not bandwidth, bounds this phase: 8-byte stores measured 2x slower).
     constexpr int WR = BM / WM, WC = BN / WN, EPS = WC + 4;          // +4 floats: conflict-free slab writes
-    constexpr int LPR8 = WC / 8, RPP8 = 64 / LPR8;                    // lanes per row (8 columns each), rows per pass
+    constexpr int LPR8 = WC / 8, RPP8 = 64 / LPR8;                    // slab read-back: lanes per row (8 columns each), rows per pass
     if (d.act == 99 || (d.flags & 4)) {      // profiling aid (flags bit 2: the same inside a captured graph) (tools/gemm_bench.py NOEPI=1): keep the accumulators live, store nothing
         float sink = 0.f;
 #pragma unroll
@@ -121,23 +137,18 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         if (sink == 1.2345e-30f) d.out_f32[0] = sink;
         return;
     }
-    __builtin_amdgcn_s_barrier();                                      // every wave is done reading the ring
-    if (d.act == 96) { if (acc[0][0][0] == 1.2345e-30f) d.out_f32[0] = acc[0][0][1]; return; }
-    float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EPS);
-    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-    const int er8 = lane / LPR8, ec8 = (lane - er8 * LPR8) * 8;        // this lane's (row, first column) in a pass
-    const bool lane_on8 = lane < RPP8 * LPR8;
+    const int px_l = lane & 15, cg = lane >> 4;                        // this lane's pixel row in a 16-row slab, its channel group
+    const bool perm = !d.geglu;
     int vstep = 0;
     if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
     const int nbase = n0 + wn * WC;
-    // vector path (8 columns per lane: 16-byte bf16 / 2 x 16-byte f32 accesses) needs 8-element aligned rows and planes
+    // vector paths (8 columns per lane: 16-byte bf16 / 2 x 16-byte f32 accesses) need 8-element aligned rows and planes
     const bool vec_ok = gridDim.z > 1 ? (d.N & 3) == 0
                                       : ((d.ldo | d.ldr | d.ldoo | d.ldv | d.N | d.of_bs | d.of_bs2 | d.oo_bs | d.oo_bs2 | d.res_bs | d.oo_lo) & 7) == 0;
     const int64_t of_base = (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2;
     const int64_t oo_base = (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2;
     const int64_t rs_base = (int64_t)zo * d.res_bs;
     float* wsp = gridDim.z > 1 ? d.ws + (int64_t)kz * d.M * d.N : nullptr;
-    constexpr int NP = (16 + RPP8 - 1) / RPP8;                         // passes per 16-row slab
     // 2x2 phase convolution of an upsample: GEMM row (img, y, x) -> output row (img, 2y + a, 2x + b); Ho, Wo powers of two
     const int up2 = d.up2_phase == 5 ? zo + 1 : d.up2_phase;
     const int lw = 31 - __builtin_clz((unsigned)(d.Wo > 0 ? d.Wo : 1)), lhw = lw + 31 - __builtin_clz((unsigned)(d.Ho > 0 ? d.Ho : 1));
@@ -148,9 +159,188 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         const int a = (up2 - 1) >> 1, bq = (up2 - 1) & 1;
         return ((int64_t)(img * 2 * d.Ho + 2 * y + a) * (2 * d.Wo)) + 2 * x + bq;
     };
-    // per-lane invariants: this lane's 8 columns are the same in every pass of every slab
-    const int ncol = nbase + ec8;
     const bool fast = vec_ok && (d.N & 7) == 0;        // every lane's 8 columns are then all inside or all outside N
+    const bool rv_hoist = d.rowvec && d.rows_per_vec >= (1 << 29) && !(d.flags & 2);
+    // ---- direct paths (accumulators -> global) ----
+    const bool plain = fast && perm && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) && d.alpha == 1.0f &&
+                       !(d.flags & 16);
+    const int ncol0 = nbase + 8 * cg;                                   // first of this lane's 8 channels of pair 0 (+32 per pair)
+    if (plain && wsp) {                                                 // split-K: raw partial sums to the workspace
+        static_for<0, TM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int m = m0 + wm * WR + i * 16 + px_l;
+            float* w = wsp + (int64_t)m * d.N + ncol0;
+            static_for<0, TJ>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                if (m < d.M && ncol0 + 32 * J < d.N) {
+                    *reinterpret_cast<f32x4*>(w + 32 * J) = acc[i][2 * J];
+                    *reinterpret_cast<f32x4*>(w + 32 * J + 4) = acc[i][2 * J + 1];
+                }
+            });
+        });
+        return;
+    }
+    bool direct = false;
+    if constexpr (NS == 1) {
+        const bool one_out = (d.out_f32 && d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
+        direct = plain && !wsp && one_out && (!d.residual || (RSTAGE && d.res_bf16 && !(d.flags & 1)));
+    } else {
+        const bool one_out = (d.out_f32 && !d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
+        direct = plain && !wsp && one_out && !(d.residual && d.res_bf16) && !up2;
+    }
+    if (direct) {
+        // bias (+ the launch-wide timestep vector: rows_per_vec >= 2^29 means ONE vector serves every row, so it is a second bias)
+        float bia[TJ][8];
+        static_for<0, TJ>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const int n = ncol0 + 32 * J;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bia[J][e] = 0.f;
+            if (n < d.N) {
+                if (d.bias) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(d.bias + n), t1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+                    bia[J][0] = t0.x; bia[J][1] = t0.y; bia[J][2] = t0.z; bia[J][3] = t0.w;
+                    bia[J][4] = t1.x; bia[J][5] = t1.y; bia[J][6] = t1.z; bia[J][7] = t1.w;
+                }
+                if (rv_hoist) {
+                    const float* rp = d.rowvec + (int64_t)vstep * d.ldv + n;
+                    const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
+                    bia[J][0] += t0.x; bia[J][1] += t0.y; bia[J][2] += t0.z; bia[J][3] += t0.w;
+                    bia[J][4] += t1.x; bia[J][5] += t1.y; bia[J][6] += t1.z; bia[J][7] += t1.w;
+                }
+            }
+        });
+        if constexpr (NS == 1) {
+            // bf16 stream / operand output.  A bf16 residual comes through LDS: the wave's [WR][WC] sub-tile is DMA'd into the
+            // idle ring (L2 -> LDS, no VGPRs, nothing waits until it is needed) and read back 16 bytes per (pixel, pair).
+            const bool has_res = d.residual != nullptr;
+            unsigned char* rstage = smem + wave * (WR * WC * 2);
+            if (has_res) {
+                if constexpr (RSTAGE) {
+                    __builtin_amdgcn_s_barrier();                          // every wave is done reading the ring
+                    constexpr int NI = WR * WC / 512;                      // 1-KiB pieces of the sub-tile
+                    const frido_bf16* rbase = reinterpret_cast<const frido_bf16*>(d.residual) + rs_base;
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        const int L = k * 64 + lane, row = L / LPR8, c8 = L - row * LPR8;
+                        int m = m0 + wm * WR + row, n = nbase + c8 * 8;
+                        m = m < d.M ? m : d.M - 1;
+                        n = n + 8 <= d.N ? n : 0;                          // columns past N: any valid address (masked later)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(rbase + (int64_t)m * d.ldr + n), (lptr_t)(rstage + k * 1024), 16, 0, 0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own DMA: no barrier needed
+                }
+            }
+            frido_bf16* obase = d.out_f32 ? reinterpret_cast<frido_bf16*>(d.out_f32) + of_base : d.out_op + oo_base;
+            const int64_t ldout = d.out_f32 ? d.ldo : d.ldoo;
+            const unsigned rsa = (unsigned)(size_t)(lptr_t)rstage + (unsigned)(px_l * LPR8 + cg) * 16u;
+            uint4 rs[2][TJ];
+            if (has_res) {
+                static_for<0, TJ>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    rs[0][J] = lds_read128u<(4 * J) * 16>(rsa);
+                });
+            }
+            static_for<0, TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (has_res) {
+                    if constexpr (i + 1 < TM) {
+                        static_for<0, TJ>([&](auto jc) {
+                            constexpr int J = decltype(jc)::value;
+                            rs[(i + 1) & 1][J] = lds_read128u<(((i + 1) * 16) * LPR8 + 4 * J) * 16>(rsa);
+                        });
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TJ) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int m = m0 + wm * WR + i * 16 + px_l;
+                frido_bf16* orow = obase + out_row(m) * ldout + ncol0;     // out_row: upsample phase interleave
+                static_for<0, TJ>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    float v[8] = {acc[i][2 * J][0] + bia[J][0], acc[i][2 * J][1] + bia[J][1], acc[i][2 * J][2] + bia[J][2], acc[i][2 * J][3] + bia[J][3],
+                                  acc[i][2 * J + 1][0] + bia[J][4], acc[i][2 * J + 1][1] + bia[J][5], acc[i][2 * J + 1][2] + bia[J][6], acc[i][2 * J + 1][3] + bia[J][7]};
+                    if (has_res) {
+                        const uint4 u = rs[i & 1][J];
+                        v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                        v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                        v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                        v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                    }
+                    if (m < d.M && ncol0 + 32 * J < d.N)
+                        *reinterpret_cast<uint4*>(orow + 32 * J) =
+                            make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                });
+            });
+        } else {
+            // bf16x3 (parity) mode: f32 stream or hi/lo operand output; an f32 residual row segment is fetched one slab ahead
+            const bool has_res = d.residual != nullptr;
+            const float* rbase = reinterpret_cast<const float*>(d.residual) + rs_base + ncol0;
+            float4 r0[2][TJ], r1[2][TJ];
+            auto fetch = [&](auto ic, auto slot) {
+                constexpr int i = decltype(ic)::value, sl = decltype(slot)::value;
+                int m = m0 + wm * WR + i * 16 + px_l;
+                m = m < d.M ? m : d.M - 1;
+                static_for<0, TJ>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    r0[sl][J] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    r1[sl][J] = r0[sl][J];
+                    if (ncol0 + 32 * J < d.N) {
+                        r0[sl][J] = *reinterpret_cast<const float4*>(rbase + (int64_t)m * d.ldr + 32 * J);
+                        r1[sl][J] = *reinterpret_cast<const float4*>(rbase + (int64_t)m * d.ldr + 32 * J + 4);
+                    }
+                });
+            };
+            if (has_res) fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            static_for<0, TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i + 1 < TM) {
+                    if (has_res) fetch(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+                }
+                const int m = m0 + wm * WR + i * 16 + px_l;
+                static_for<0, TJ>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    float v[8] = {acc[i][2 * J][0] + bia[J][0], acc[i][2 * J][1] + bia[J][1], acc[i][2 * J][2] + bia[J][2], acc[i][2 * J][3] + bia[J][3],
+                                  acc[i][2 * J + 1][0] + bia[J][4], acc[i][2 * J + 1][1] + bia[J][5], acc[i][2 * J + 1][2] + bia[J][6], acc[i][2 * J + 1][3] + bia[J][7]};
+                    if (has_res) {
+                        const float4 a = r0[i & 1][J], b = r1[i & 1][J];
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                    }
+                    if (m < d.M && ncol0 + 32 * J < d.N) {
+                        if (d.out_f32) {
+                            float* o = d.out_f32 + of_base + (int64_t)m * d.ldo + ncol0 + 32 * J;
+                            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else {
+                            uint32_t h[8], l[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+                            frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + ncol0 + 32 * J;
+                            *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                            *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+                        }
+                    }
+                });
+            });
+        }
+        return;
+    }
+
+    // ---- paths through LDS: each 16-row slab of the wave's sub-tile is written to the (now idle) ring as [pixel][channel] f32
+    //      and read back so that every lane owns 8 consecutive columns of one row (activations, GEGLU, two outputs, row
+    //      vectors, ragged shapes).  A lane's four accumulator values of a tile are four consecutive channels: one
+    //      ds_write_b128 per tile.
+    __builtin_amdgcn_s_barrier();                                      // every wave is done reading the ring
+    if (d.act == 96) { if (acc[0][0][0] == 1.2345e-30f) d.out_f32[0] = acc[0][0][1]; return; }
+    float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EPS);
+    const int er8 = lane / LPR8, ec8 = (lane - er8 * LPR8) * 8;        // this lane's (row, first column) in a read-back pass
+    const bool lane_on8 = lane < RPP8 * LPR8;
+    constexpr int NP = (16 + RPP8 - 1) / RPP8;                         // passes per 16-row slab
+    const int ncol = nbase + ec8;
+    // slab column of tile j's four values of this lane
+    auto slab_col = [&](int j) { return perm ? 32 * (j >> 1) + 8 * cg + 4 * (j & 1) : 16 * j + 4 * cg; };
     float bia[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bia[e] = 0.f;
@@ -158,235 +348,44 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         const float4 t0 = *reinterpret_cast<const float4*>(d.bias + ncol), t1 = *reinterpret_cast<const float4*>(d.bias + ncol + 4);
         bia[0] = t0.x; bia[1] = t0.y; bia[2] = t0.z; bia[3] = t0.w; bia[4] = t1.x; bia[5] = t1.y; bia[6] = t1.z; bia[7] = t1.w;
     }
-    // Sampler mode (rows_per_vec >= 2^29): ONE timestep vector serves every row of the launch, so it is a second bias.  Read
-    // per pass it was a dependent L2 round trip in front of every store (the epilogue of a 64^2 conv took 14 us of its 57).
-    const bool rv_hoist = d.rowvec && d.rows_per_vec >= (1 << 29) && !(d.flags & 2);
     if (fast && rv_hoist && !wsp && !d.geglu && lane_on8 && ncol < d.N) {
         const float* rp = d.rowvec + (int64_t)vstep * d.ldv + ncol;
         const float4 t0 = *reinterpret_cast<const float4*>(rp), t1 = *reinterpret_cast<const float4*>(rp + 4);
         bia[0] += t0.x; bia[1] += t0.y; bia[2] += t0.z; bia[3] += t0.w; bia[4] += t1.x; bia[5] += t1.y; bia[6] += t1.z; bia[7] += t1.w;
     }
-    // bf16 residual: this wave's [WR][WC] sub-tile goes L2 -> LDS by DMA right now (the ring is idle, no VGPRs, nothing waits
-    // for it until the first slab has been transposed) instead of one dependent global load per pass.
-    const bool res_stage = RSTAGE && fast && d.residual && d.res_bf16 && !wsp && !d.geglu && !(d.flags & 1);
-    constexpr int RS_BASE = WM * WN * 16 * EPS * 4;                       // behind every wave's transpose slab
-    unsigned char* rstage = smem + RS_BASE + wave * (WR * WC * 2);
-    if (res_stage) {
-        constexpr int NI = WR * WC / 512;                                  // 1-KiB pieces of the sub-tile
-        const frido_bf16* rbase = reinterpret_cast<const frido_bf16*>(d.residual) + rs_base;
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int L = k * 64 + lane, row = L / LPR8, c8 = L - row * LPR8;
-            int m = m0 + wm * WR + row, n = nbase + c8 * 8;
-            m = m < d.M ? m : d.M - 1;
-            n = n + 8 <= d.N ? n : 0;                                      // columns past N: any valid address (masked later)
-            __builtin_amdgcn_global_load_lds((gptr_t)(rbase + (int64_t)m * d.ldr + n), (lptr_t)(rstage + k * 1024), 16, 0, 0);
-        }
-    }
-    bool res_wait = res_stage;
-    // GEGLU (attention.py:42-44): the projection's rows are packed so that 16-column blocks alternate [a | gate]; a value and
-    // its gate are then the SAME element of adjacent accumulator fragments, so a * gelu(gate) is formed in registers and only
-    // the WC/2 outputs go through the LDS transposition (half the slab traffic of transposing both).
-    float gba[TN / 2 > 0 ? TN / 2 : 1], gbg[TN / 2 > 0 ? TN / 2 : 1];
+    // GEGLU (attention.py:42-44): the projection's rows are packed so that 16-row blocks alternate [a | gate] and the launch keeps
+    // the identity row order: a value and its gate are then the SAME element of adjacent accumulator fragments, so
+    // a * gelu(gate) is formed in registers and only the WC/2 outputs go through the LDS transposition.
+    float gba[TJ][4], gbg[TJ][4];
     if (d.geglu) {
 #pragma unroll
-        for (int jo = 0; jo < TN / 2; ++jo) {
-            const int n = nbase + jo * 32 + col_l;
-            gba[jo] = d.bias && n + 16 < d.N ? d.bias[n] : 0.f;
-            gbg[jo] = d.bias && n + 16 < d.N ? d.bias[n + 16] : 0.f;
-        }
-    }
-    // ---- streamlined path: bf16 output (stream or operand), bias (+ hoisted timestep vector) (+ staged bf16 residual), no
-    //      activation / alpha / row bias.  This is every 3x3 conv and most GEMMs of the bf16 sampler.  r02: inside the replayed
-    //      graph the general slab loop below cost 0.86 ms of a 7.5 ms forward WITHOUT its stores (profiles/
-    //      r02_epilogue_in_graph.txt): hipcc fences every C++ LDS read of a kernel that also issues LDS-DMA with
-    //      s_waitcnt vmcnt(0), and on CDNA4 vmcnt counts STORES too -- each pass waited for the previous pass's global
-    //      store -- and the descriptor's run-time switches were ~40 scalar branches per pass.  Here every LDS access is
-    //      inline asm (counted by hand with one lgkmcnt(0) per slab), the four passes of a slab are unrolled (their reads
-    //      issue back to back) and the slabs are unrolled (static accumulator indices, no copies).
-    if constexpr (NS == 1) {
-        const bool one_out = (d.out_f32 && d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
-        const bool simple = fast && !wsp && !d.geglu && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) &&
-                            (!d.residual || res_stage) && d.alpha == 1.0f && one_out && !(d.flags & 16);
-        if (simple) {
-            if (res_stage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's residual sub-tile has landed
-            frido_bf16* obase = d.out_f32 ? reinterpret_cast<frido_bf16*>(d.out_f32) + of_base : d.out_op + oo_base;
-            const int64_t ldout = d.out_f32 ? d.ldo : d.ldoo;
-            const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-            const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;       // slab write address of this lane
-            const unsigned ra = lds0 + (unsigned)((wave * 16 + er8) * EPS + ec8) * 4u;          // read-back address (pass 0)
-            const unsigned rsa = (unsigned)(size_t)(lptr_t)rstage + (unsigned)(er8 * LPR8 + (ec8 >> 3)) * 16u;
-            const bool col_ok = lane_on8 && ncol < d.N;
-            const bool has_res = res_stage;
-            static_for<0, TM>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                static_for<0, TN>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    lds_write32<(0 * EPS + j * 16) * 4>(wa, acc[i][j][0]);
-                    lds_write32<(1 * EPS + j * 16) * 4>(wa, acc[i][j][1]);
-                    lds_write32<(2 * EPS + j * 16) * 4>(wa, acc[i][j][2]);
-                    lds_write32<(3 * EPS + j * 16) * 4>(wa, acc[i][j][3]);
-                });
-                float4 lo[NP], hi[NP];
-                uint4 rs[NP];
-                static_for<0, NP>([&](auto pc) {
-                    constexpr int pp = decltype(pc)::value;
-                    lo[pp] = lds_read128f<pp * RPP8 * EPS * 4>(ra);
-                    hi[pp] = lds_read128f<pp * RPP8 * EPS * 4 + 16>(ra);
-                    if (has_res) rs[pp] = lds_read128u<(i * 16 + pp * RPP8) * LPR8 * 16>(rsa);
-                });
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, NP>([&](auto pc) {
-                    constexpr int pp = decltype(pc)::value;
-                    const int r = pp * RPP8 + er8;
-                    const int m = m0 + wm * WR + i * 16 + r;
-                    if (col_ok && r < 16 && m < d.M) {
-                        float v[8] = {lo[pp].x + bia[0], lo[pp].y + bia[1], lo[pp].z + bia[2], lo[pp].w + bia[3],
-                                      hi[pp].x + bia[4], hi[pp].y + bia[5], hi[pp].z + bia[6], hi[pp].w + bia[7]};
-                        if (has_res) {
-                            const uint4 u = rs[pp];
-                            v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                            v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                            v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                            v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
-                        }
-                        *reinterpret_cast<uint4*>(obase + out_row(m) * ldout + ncol) =      // out_row: upsample phase interleave
-                            make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-                    }
-                });
-            });
-            return;
-        }
-    }
-    // ---- bf16x3 (parity) mode: f32 stream or hi/lo operand output, bias (+ hoisted timestep vector), optional f32 residual whose
-    //      rows are fetched at the top of their slab (one load round trip per slab instead of one per pass)
-    if constexpr (NS == 2) {
-        const bool one_out = (d.out_f32 && !d.out_bf16 && !d.out_op) || (d.out_op && !d.out_f32);
-        const bool simple2 = fast && !wsp && !d.geglu && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) &&
-                             !(d.residual && d.res_bf16) && !up2 && d.alpha == 1.0f && one_out && !(d.flags & 16);
-        if (simple2) {
-            const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-            const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;
-            const unsigned ra = lds0 + (unsigned)((wave * 16 + er8) * EPS + ec8) * 4u;
-            const bool col_ok = lane_on8 && ncol < d.N;
-            const bool has_res = d.residual != nullptr;
-            const float* rbase = reinterpret_cast<const float*>(d.residual) + rs_base + ncol;
-            static_for<0, TM>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                float4 r0[NP], r1[NP];
-                if (has_res) {
-                    static_for<0, NP>([&](auto pc) {
-                        constexpr int pp = decltype(pc)::value;
-                        const int r = pp * RPP8 + er8;
-                        int m = m0 + wm * WR + i * 16 + r;
-                        m = m < d.M ? m : d.M - 1;
-                        r0[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        r1[pp] = r0[pp];
-                        if (col_ok) {
-                            r0[pp] = *reinterpret_cast<const float4*>(rbase + (int64_t)m * d.ldr);
-                            r1[pp] = *reinterpret_cast<const float4*>(rbase + (int64_t)m * d.ldr + 4);
-                        }
-                    });
-                }
-                static_for<0, TN>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    lds_write32<(0 * EPS + j * 16) * 4>(wa, acc[i][j][0]);
-                    lds_write32<(1 * EPS + j * 16) * 4>(wa, acc[i][j][1]);
-                    lds_write32<(2 * EPS + j * 16) * 4>(wa, acc[i][j][2]);
-                    lds_write32<(3 * EPS + j * 16) * 4>(wa, acc[i][j][3]);
-                });
-                float4 lo[NP], hi[NP];
-                static_for<0, NP>([&](auto pc) {
-                    constexpr int pp = decltype(pc)::value;
-                    lo[pp] = lds_read128f<pp * RPP8 * EPS * 4>(ra);
-                    hi[pp] = lds_read128f<pp * RPP8 * EPS * 4 + 16>(ra);
-                });
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, NP>([&](auto pc) {
-                    constexpr int pp = decltype(pc)::value;
-                    const int r = pp * RPP8 + er8;
-                    const int m = m0 + wm * WR + i * 16 + r;
-                    if (col_ok && r < 16 && m < d.M) {
-                        float v[8] = {lo[pp].x + bia[0], lo[pp].y + bia[1], lo[pp].z + bia[2], lo[pp].w + bia[3],
-                                      hi[pp].x + bia[4], hi[pp].y + bia[5], hi[pp].z + bia[6], hi[pp].w + bia[7]};
-                        if (has_res) {
-                            v[0] += r0[pp].x; v[1] += r0[pp].y; v[2] += r0[pp].z; v[3] += r0[pp].w;
-                            v[4] += r1[pp].x; v[5] += r1[pp].y; v[6] += r1[pp].z; v[7] += r1[pp].w;
-                        }
-                        if (d.out_f32) {
-                            float* o = d.out_f32 + of_base + (int64_t)m * d.ldo + ncol;
-                            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                        } else {
-                            uint32_t h[8], l[8];
+        for (int jo = 0; jo < TJ; ++jo)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
-                            frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + ncol;
-                            *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-                            *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-                        }
-                    }
-                });
-            });
-            return;
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int n = nbase + jo * 32 + 4 * cg + e;
+                gba[jo][e] = d.bias && n + 16 < d.N ? d.bias[n] : 0.f;
+                gbg[jo][e] = d.bias && n + 16 < d.N ? d.bias[n + 16] : 0.f;
+            }
     }
-    // ---- the same treatment for the two other hot forms: split-K partial sums (raw f32 slabs to the workspace) and the fused
-    //      GEGLU projection (a * gelu(gate) formed in registers, operand output)
-    if (fast && wsp && !(d.flags & 48)) {
-        const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-        const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;
-        const unsigned ra = lds0 + (unsigned)((wave * 16 + er8) * EPS + ec8) * 4u;
-        const bool col_ok = lane_on8 && ncol < d.N;
-        static_for<0, TM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            static_for<0, TN>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                lds_write32<(0 * EPS + j * 16) * 4>(wa, acc[i][j][0]);
-                lds_write32<(1 * EPS + j * 16) * 4>(wa, acc[i][j][1]);
-                lds_write32<(2 * EPS + j * 16) * 4>(wa, acc[i][j][2]);
-                lds_write32<(3 * EPS + j * 16) * 4>(wa, acc[i][j][3]);
-            });
-            float4 lo[NP], hi[NP];
-            static_for<0, NP>([&](auto pc) {
-                constexpr int pp = decltype(pc)::value;
-                lo[pp] = lds_read128f<pp * RPP8 * EPS * 4>(ra);
-                hi[pp] = lds_read128f<pp * RPP8 * EPS * 4 + 16>(ra);
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, NP>([&](auto pc) {
-                constexpr int pp = decltype(pc)::value;
-                const int r = pp * RPP8 + er8;
-                const int m = m0 + wm * WR + i * 16 + r;
-                if (col_ok && r < 16 && m < d.M) {
-                    float* w = wsp + (int64_t)m * d.N + ncol;
-                    *reinterpret_cast<float4*>(w) = lo[pp];
-                    *reinterpret_cast<float4*>(w + 4) = hi[pp];
-                }
-            });
-        });
-        return;
-    }
-    if constexpr (NS == 1 && (TN % 2) == 0) {
+    if constexpr (NS == 1) {
+        // the fused GEGLU projection of the bf16 sampler: every LDS access in inline asm, one hand-counted lgkmcnt(0) per slab
+        // (hipcc fences C++ LDS reads of a kernel that issues LDS-DMA with vmcnt(0), which on CDNA4 also waits for STORES)
         if (d.geglu && d.out_op && d.alpha == 1.0f && !(d.flags & 80)) {
             constexpr int OC = WC / 2, LPRG = OC / 8, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16, NPG = (16 + RPPG - 1) / RPPG;
             const int gr = lane / LPRG, oc = (lane - gr * LPRG) * 8;          // row, first output column of this lane
             const int no = (nbase >> 1) + oc;
             const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-            const unsigned wa = lds0 + (unsigned)((wave * 16 + row_l) * EPS + col_l) * 4u;
+            const unsigned wa = lds0 + (unsigned)((wave * 16 + px_l) * EPS + 4 * cg) * 4u;
             const unsigned ra = lds0 + (unsigned)((wave * 16 + gr) * EPS + oc) * 4u;
             const bool col_ok = lane < RPPG * LPRG && no + 7 < (d.N >> 1);
             static_for<0, TM>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                static_for<0, TN / 2>([&](auto jc) {
+                static_for<0, TJ>([&](auto jc) {
                     constexpr int jo = decltype(jc)::value;
-                    lds_write32<(0 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][0] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][0] + gbg[jo]));
-                    lds_write32<(1 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][1] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][1] + gbg[jo]));
-                    lds_write32<(2 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][2] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][2] + gbg[jo]));
-                    lds_write32<(3 * EPS + jo * 16) * 4>(wa, (acc[i][2 * jo][3] + gba[jo]) * gelu_f(acc[i][2 * jo + 1][3] + gbg[jo]));
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (acc[i][2 * jo][e] + gba[jo][e]) * gelu_f(acc[i][2 * jo + 1][e] + gbg[jo][e]);
+                    lds_write128<jo * 16 * 4>(wa, o);
                 });
                 float4 lo[NPG], hi[NPG];
                 static_for<0, NPG>([&](auto pc) {
@@ -403,8 +402,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                     if (col_ok && r < 16 && m < d.M) {
                         const float4 a = lo[pp], b = hi[pp];
                         *reinterpret_cast<uint4*>(d.out_op + (int64_t)m * d.ldoo + no) =
-                            make_uint4(f32_to_bf16_bits(a.x) | (f32_to_bf16_bits(a.y) << 16), f32_to_bf16_bits(a.z) | (f32_to_bf16_bits(a.w) << 16),
-                                       f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16), f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16));
+                            make_uint4(pack2_bf16(a.x, a.y), pack2_bf16(a.z, a.w), pack2_bf16(b.x, b.y), pack2_bf16(b.z, b.w));
                     }
                 });
             });
@@ -423,10 +421,12 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             }
         if (d.geglu) {
 #pragma unroll
-            for (int jo = 0; jo < TN / 2; ++jo)
+            for (int jo = 0; jo < TJ; ++jo) {
+                f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ep[(row_l + e) * EPS + jo * 16 + col_l] = fmaf(sel[2 * jo][e], d.alpha, gba[jo]) * gelu_f(fmaf(sel[2 * jo + 1][e], d.alpha, gbg[jo]));
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(sel[2 * jo][e], d.alpha, gba[jo][e]) * gelu_f(fmaf(sel[2 * jo + 1][e], d.alpha, gbg[jo][e]));
+                *reinterpret_cast<f32x4*>(ep + px_l * EPS + jo * 16 + 4 * cg) = o;
+            }
             constexpr int OC = WC / 2;                                        // output columns of this wave
             constexpr int LPRG = OC / 8, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16;
             const int gr = lane / LPRG, oc = (lane - gr * LPRG) * 8;          // row, first output column of this lane
@@ -450,13 +450,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             continue;
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ep[(row_l + e) * EPS + j * 16 + col_l] = sel[j][e];
-        if (res_wait) {                     // the staged residual tile has landed (this wave's own DMA: no barrier needed)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            res_wait = false;
-        }
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(ep + px_l * EPS + slab_col(j)) = sel[j];
         if (!fast) {
             // generic element-wise path (ragged N or unaligned strides: the 3-channel output conv, odd test shapes).  Rolled
             // and scalar on purpose: unrolled per-element fallbacks inside the vector path tripled the kernel's code size.
@@ -519,8 +513,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             if (d.residual) {
                 const int64_t ro = rs_base + (int64_t)m * d.ldr + n;
                 if (d.res_bf16) {
-                    const uint4 u = res_stage ? *reinterpret_cast<const uint4*>(rstage + ((i * 16 + r) * LPR8 + (ec8 >> 3)) * 16)
-                                              : *reinterpret_cast<const uint4*>(reinterpret_cast<const frido_bf16*>(d.residual) + ro);
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const frido_bf16*>(d.residual) + ro);
                     v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
                     v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
                     v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
@@ -641,7 +634,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         const int row = (wave + NW * j) * CHR + lrow;
-        int n = n0 + row;
+        int n = n0 + (d.geglu ? row : chan_of_pos(row));      // LDS row `row` holds channel chan_of_pos(row): see tile_epilogue
         n = n < d.N ? n : d.N - 1;
         b_off[j] = (int64_t)n * d.ldb + lq * 8;
     }
@@ -786,11 +779,12 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    // weights first: the accumulator tile is C^T (a lane owns 4 consecutive channels of one pixel)
                     if (NS == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][0], fa[1][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][1], fa[0][i], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[j & 1][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][0], fa[0][i], acc[i][j], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -975,7 +969,7 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&ac
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j & 1], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1027,7 +1021,7 @@ __device__ __forceinline__ void patch_skip_loop(const PatchCtx<BN, NW>& cx, f32x
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j & 1], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1096,7 +1090,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
     int64_t b_off[LPBMAX];
 #pragma unroll
     for (int j = 0; j < LPBMAX; ++j) {
-        int n = n0 + (wave + NW * j) * 16 + lrow;
+        int n = n0 + chan_of_pos((wave + NW * j) * 16 + lrow);      // permuted weight rows: see tile_epilogue
         n = n < d.N ? n : d.N - 1;
         b_off[j] = (int64_t)n * d.ldb + lq * 8;
     }
@@ -1235,7 +1229,7 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j & 1], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- advance ----
