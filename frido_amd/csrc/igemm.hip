@@ -702,6 +702,21 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         }
     };
 
+    // one DMA piece of a stage (bf16 mode only: pieces 0..JA-1 = A chunks, JA..JA+JB-1 = B chunks); issue_begin / issue_end bracket a stage
+    auto issue_begin = [&]() { if (seg_left == 0) retap(); };
+    auto issue_piece = [&](auto pc, int buf) {
+        constexpr int pi = decltype(pc)::value;
+        unsigned char* sb = smem + buf * STAGE + wave * 1024;
+        if constexpr (pi < JA) {
+            __builtin_amdgcn_global_load_lds((gptr_t)aptr[pi], (lptr_t)(sb + pi * (NW * 1024)), 16, 0, 0);
+            aptr[pi] += astep[pi];
+        } else {
+            constexpr int j = pi - JA;
+            __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+            bptr[j] += BK;
+        }
+    };
+    auto issue_end = [&]() { ++ktn; --seg_left; };
     auto issue = [&](int buf) {
         if (seg_left == 0) retap();
         unsigned char* sb = smem + buf * STAGE + wave * 1024;
@@ -739,6 +754,101 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * ROWB;
     const unsigned b_frag = lds0 + BM * ROWB + (wn * (BN / WN) + frow) * ROWB;
 
+    if constexpr (NS == 1 && BK == 64) {
+        // ---- software-pipelined main loop (bf16 mode, BK = 64 tiles).  The fragments of k-step t+1 are read from LDS into a SECOND register set
+        //      while the MFMAs of k-step t issue from the first: with one workgroup of 8 waves per CU (or two of 4) the waves
+        //      of a SIMD run in lockstep between barriers, so in the plain loop (below, kept for bf16x3 where the second set
+        //      does not fit) the matrix pipe idled through every read phase -- 256 x 128 tile: 1100 cycles per k-tile for
+        //      512 cycles of MFMA work.  Measured per tile (tools/_gb_pipe.sh): BK = 64 tiles -8...-12 % per launch; BK = 32 tiles
+        //      +-0 (128 x 128, 256 x 128) or spilling (128 x 192, 256 x 256), so they keep the plain loop.  Ring protocol: a stage is free as soon as every wave holds its fragments in
+        //      registers, i.e. at the barrier that publishes the NEXT stage, so all D slots carry loads (one more in flight).
+        auto wait_younger = [&](int younger) {                  // stages issued after the one waited for (loads retire in order)
+            switch (younger) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<(D > 1 ? 1 : 0) * G::LPT>(); break;
+                case 2: wait_vmcnt<(D > 2 ? 2 : 0) * G::LPT>(); break;
+                case 3: wait_vmcnt<(D > 3 ? 3 : 0) * G::LPT>(); break;
+                case 4: wait_vmcnt<(D > 4 ? 4 : 0) * G::LPT>(); break;
+                default: wait_vmcnt<(D > 5 ? 5 : 0) * G::LPT>(); break;
+            }
+        };
+        static_assert(D <= 6 && (D - 1) * G::LPT < 64, "vmcnt immediate");
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < nk) issue(s);
+        bf16x8 fa[2][TM], fb[2][TN];
+        // fragment r of a k-step: r < TN -> weight tile r, else pixel tile r - TN
+        auto read_frag = [&](auto setc, auto rc, unsigned sa, unsigned sbb) {
+            constexpr int set = decltype(setc)::value, r = decltype(rc)::value;
+            if constexpr (r < TN) fb[set][r] = lds_read128(sbb + r * 16 * ROWB);
+            else fa[set][r - TN] = lds_read128(sa + (r - TN) * 16 * ROWB);
+        };
+        constexpr int NR = TM + TN;
+        if (nk > 0) {
+            wait_younger(nk - 1 < D - 1 ? nk - 1 : D - 1);
+            __builtin_amdgcn_s_barrier();
+            static_for<0, NR>([&](auto rc) { read_frag(std::integral_constant<int, 0>{}, rc, a_frag + fslot0, b_frag + fslot0); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        int buf = 0;
+        // one k-STEP (32 k) per call; P = register set holding this step's fragments.  The reads of the next step's fragments are
+        // dealt over the TN MFMA groups of this step (a group = one weight tile x TM pixel tiles), the next stage's DMA
+        // goes out after the first group: the matrix pipe has work queued while the wave issues memory instructions.
+        auto step = [&](auto pc, auto prec, int kt, int ks) {
+            constexpr int P = decltype(pc)::value;
+            constexpr bool PRE = decltype(prec)::value;            // a next step exists: prefetch its fragments
+            const bool last_ks = ks == KS - 1;
+            const int nbuf = buf + 1 == D ? 0 : buf + 1;
+            bool dma = false;                                      // refill this stage's slot during this step?
+            int rbuf = buf, rks = ks + 1;
+            if (last_ks) {
+                rbuf = nbuf; rks = 0;
+                if (PRE) {
+                    // stage kt+1 must have landed; after this barrier every wave holds stage kt in registers: its slot is free
+                    if (kt + D - 1 < nk) wait_vmcnt<(D - 2) * G::LPT>();
+                    else wait_younger(nk - kt - 2);
+                    __builtin_amdgcn_s_barrier();
+                    dma = kt + D < nk;
+                }
+            }
+            const int fs = rks ? fslot1 : fslot0;
+            const unsigned sa = a_frag + rbuf * STAGE + fs, sbb = b_frag + rbuf * STAGE + fs;
+            if (dma) issue_begin();
+            constexpr int NPC = JA + JB;
+            static_for<0, TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (PRE) {
+                    static_for<j * NR / TN, (j + 1) * NR / TN>([&](auto rc) { read_frag(std::integral_constant<int, 1 - P>{}, rc, sa, sbb); });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[P][i], acc[i][j], 0, 0, 0);   // weights first: C^T tiles
+                __builtin_amdgcn_sched_barrier(0);
+                if (dma) {
+                    static_for<j * NPC / TN, (j + 1) * NPC / TN>([&](auto qc) { issue_piece(qc, buf); });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (dma) issue_end();
+            if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (last_ks) buf = nbuf;
+        };
+        const int nsteps = nk * KS;
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        int st = 0;
+        for (; st + 2 < nsteps; st += 2) {
+            step(std::integral_constant<int, 0>{}, T_{}, st / KS, st % KS);
+            step(std::integral_constant<int, 1>{}, T_{}, (st + 1) / KS, (st + 1) % KS);
+        }
+        if (st + 2 == nsteps) {
+            step(std::integral_constant<int, 0>{}, T_{}, st / KS, st % KS);
+            step(std::integral_constant<int, 1>{}, F_{}, (st + 1) / KS, (st + 1) % KS);
+        } else if (st + 1 == nsteps) {
+            step(std::integral_constant<int, 0>{}, F_{}, st / KS, st % KS);
+        }
+    } else {
     // ---- prologue: fill D-1 stages ----
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
@@ -790,6 +900,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             }
         }
         buf = buf + 1 == D ? 0 : buf + 1;
+    }
+
     }
 
     tile_epilogue<BM, BN, NS, WM, G::RSTAGE>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz);
