@@ -162,6 +162,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
             }
     };
 
+    // the same pieces one SLOT at a time (slot s < NPK: K piece wave + NW s, else V^T piece wave + NW (s - NPK)): the
+    // double-buffered loop deals the next tile's slots over the k-steps of S^T = K Q^T instead of issuing all of them
+    // (12 per wave at d = 384, 60-185 cycles each) in front of the first MFMA
+    constexpr int NPK = (G::KP + NW - 1) / NW, NPV = (G::VP + NW - 1) / NW, NSLOT = NPK + NPV;
+    auto issue_slot = [&](int sl, const frido_bf16* ksrc, const frido_bf16* vsrc, int buf) {      // sl: constant after unrolling
+        if (sl < NPK) {
+            const int piece = wave + NW * sl;
+            if (piece < G::KP) {
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ksrc + (p ? d.k_lo : 0) + (piece >> 1) * 32),
+                                                     (lptr_t)(smem + buf * G::TILE + p * G::KPL + piece * 1024), 16, 0, 0);
+            }
+        } else {
+            const int piece = wave + NW * (sl - NPK);
+            if (piece < G::VP) {
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(vsrc + (p ? d.vt_lo : 0) + (int64_t)piece * 16 * d.ldvt),
+                                                     (lptr_t)(smem + buf * G::TILE + G::KBUF + p * G::VPL + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
     // fragment read address inside a [16 rows][64 B] chunk: row r, logical slot g
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned frag = (unsigned)(r * 64 + ((g ^ ((4 - ((r >> 2) & 3)) & 3)) << 4));
@@ -183,12 +206,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
         if constexpr (G::DBUF) {
             k_frag += (j & 1) * G::TILE;
             v_frag += (j & 1) * G::TILE;
-            if (j + 1 < ntiles) {
-                issue_k(j + 1, (j + 1) & 1);
-                issue_v(j + 1, (j + 1) & 1);
-            }
         } else {
             issue_v(j);
+        }
+        const bool nxt = G::DBUF && j + 1 < ntiles;          // deal tile j + 1's DMA slots over the k-steps below
+        const frido_bf16* ksrc_n = Kb;
+        const frido_bf16* vsrc_n = Vb + (j + 1) * G::BKV;
+        if (nxt) {
+            int key = (j + 1) * G::BKV + key_l;
+            key = key < d.Nk ? key : d.Nk - 1;
+            ksrc_n = Kb + (int64_t)key * d.ldk;
         }
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
         {
@@ -220,6 +247,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
                 }
                 s0 = mma3<NS>(kf[ks & (NB - 1)][0], qf[ks], s0);
                 s1 = mma3<NS>(kf[ks & (NB - 1)][1], qf[ks], s1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (nxt) {
+#pragma unroll
+                    for (int sl = ks * NSLOT / KS; sl < (ks + 1) * NSLOT / KS; ++sl) issue_slot(sl, ksrc_n, vsrc_n, (j + 1) & 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

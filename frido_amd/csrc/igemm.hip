@@ -40,6 +40,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// dispatch-order id of this workgroup within its batch slice -> work item (see igemm_kernel): XCD x = id & 7 takes items
+// [start(x), start(x) + count(x)) of the nb * gridDim.z items
+__device__ __forceinline__ int xcd_item(int nb, int) {
+    const int total = nb * (int)gridDim.z;
+    const int id = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = id & 7, loc = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 template <int BM, int BN, int NS, int BK>
 struct Geo {
     static constexpr int WMW = BM >= 256 ? 4 : 2;           // waves along M (x 2 along N): 4 or 8 waves per workgroup
@@ -162,8 +171,8 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
     const bool fast = vec_ok && (d.N & 7) == 0;        // every lane's 8 columns are then all inside or all outside N
     const bool rv_hoist = d.rowvec && d.rows_per_vec >= (1 << 29) && !(d.flags & 2);
     // ---- direct paths (accumulators -> global) ----
-    const bool plain = fast && perm && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) && d.alpha == 1.0f &&
-                       !(d.flags & 16);
+    const bool plain = fast && perm && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) && !(d.flags & 16);
+    const float alpha = d.alpha;                                        // (split-K partials stay raw: the reduce kernel scales)
     const int ncol0 = nbase + 8 * cg;                                   // first of this lane's 8 channels of pair 0 (+32 per pair)
     if (plain && wsp) {                                                 // split-K: raw partial sums to the workspace
         static_for<0, TM>([&](auto ic) {
@@ -259,8 +268,10 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 frido_bf16* orow = obase + out_row(m) * ldout + ncol0;     // out_row: upsample phase interleave
                 static_for<0, TJ>([&](auto jc) {
                     constexpr int J = decltype(jc)::value;
-                    float v[8] = {acc[i][2 * J][0] + bia[J][0], acc[i][2 * J][1] + bia[J][1], acc[i][2 * J][2] + bia[J][2], acc[i][2 * J][3] + bia[J][3],
-                                  acc[i][2 * J + 1][0] + bia[J][4], acc[i][2 * J + 1][1] + bia[J][5], acc[i][2 * J + 1][2] + bia[J][6], acc[i][2 * J + 1][3] + bia[J][7]};
+                    float v[8] = {fmaf(acc[i][2 * J][0], alpha, bia[J][0]), fmaf(acc[i][2 * J][1], alpha, bia[J][1]),
+                                  fmaf(acc[i][2 * J][2], alpha, bia[J][2]), fmaf(acc[i][2 * J][3], alpha, bia[J][3]),
+                                  fmaf(acc[i][2 * J + 1][0], alpha, bia[J][4]), fmaf(acc[i][2 * J + 1][1], alpha, bia[J][5]),
+                                  fmaf(acc[i][2 * J + 1][2], alpha, bia[J][6]), fmaf(acc[i][2 * J + 1][3], alpha, bia[J][7])};
                     if (has_res) {
                         const uint4 u = rs[i & 1][J];
                         v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
@@ -301,8 +312,10 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 const int m = m0 + wm * WR + i * 16 + px_l;
                 static_for<0, TJ>([&](auto jc) {
                     constexpr int J = decltype(jc)::value;
-                    float v[8] = {acc[i][2 * J][0] + bia[J][0], acc[i][2 * J][1] + bia[J][1], acc[i][2 * J][2] + bia[J][2], acc[i][2 * J][3] + bia[J][3],
-                                  acc[i][2 * J + 1][0] + bia[J][4], acc[i][2 * J + 1][1] + bia[J][5], acc[i][2 * J + 1][2] + bia[J][6], acc[i][2 * J + 1][3] + bia[J][7]};
+                    float v[8] = {fmaf(acc[i][2 * J][0], alpha, bia[J][0]), fmaf(acc[i][2 * J][1], alpha, bia[J][1]),
+                                  fmaf(acc[i][2 * J][2], alpha, bia[J][2]), fmaf(acc[i][2 * J][3], alpha, bia[J][3]),
+                                  fmaf(acc[i][2 * J + 1][0], alpha, bia[J][4]), fmaf(acc[i][2 * J + 1][1], alpha, bia[J][5]),
+                                  fmaf(acc[i][2 * J + 1][2], alpha, bia[J][6]), fmaf(acc[i][2 * J + 1][3], alpha, bia[J][7])};
                     if (has_res) {
                         const float4 a = r0[i & 1][J], b = r1[i & 1][J];
                         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
@@ -567,11 +580,13 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     const int tiles_n = (d.N + BN - 1) / BN;
     const int tiles_m = (d.M + BM - 1) / BM;
     const int nb = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+    // Work items = (k-slice, tile), k-slice slowest; workgroups are dealt to the 8 XCDs round-robin in dispatch order
+    // (x fastest, then z), and XCD x takes a CONTIGUOUS range of items: neighbouring tiles share an A row panel, and under
+    // split-K an XCD works on ONE k-slice (or a few), so its L2 holds that slice of the weights once.  Before (k-slice =
+    // blockIdx.z, every XCD walked all slices): the 8x8-plane convs (M = 1024, split 8) fetched 72 MB per launch from
+    // MALL / HBM for 18.6 MB of operands (tools/_pmc_smallm.sh).
+    const int kz = xcd_item(nb, tiles_n) / nb;
+    const int bid = xcd_item(nb, tiles_n) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     // batch index, optionally two-level (outer x inner, e.g. image x head)
@@ -641,7 +656,6 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 
     // k-tile range of this workgroup (split-K: gridDim.z slices)
     const int nk_all = (d.K + d.K2) / BK;
-    const int kz = blockIdx.z;
     const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kt0 = kz * per;
     const int nk = max(0, min(nk_all, kt0 + per) - kt0);
@@ -1045,8 +1059,11 @@ __device__ __forceinline__ void patch_issue_skip(const PatchCtx<BN, NW>& cx, int
 }
 
 // MODE 0: a conv chunk follows; 1: nothing follows; 2: last conv chunk, skip chunks follow
+// The pixel fragments of tap T+1 come from the SAME resident patch (tap 8: from the next chunk's patch, published since its
+// tap 3), so they are read into the other half of fa[2][4] under this tap's MFMAs; only the weight fragments, which need
+// this tap's barrier, are read just in time.  After the barrier a wave waits for ONE ds_read instead of five.
 template <int BN, int NW, int T, int MODE>
-__device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c) {
+__device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], bf16x8 (&fa)[2][4], bool have, int c) {
     using P = PGeo<BN, NW>;
     constexpr int TM = 4, TN = BN / 32;
     // loads issued after the weight stage of tap T (in-order retirement) may stay in flight: the next tap's stage, plus the next
@@ -1064,8 +1081,38 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&ac
     else if constexpr (MODE == 0) patch_issue_b<BN, NW>(cx, c + 1, T - 7, (T + 2) % 3);
     else if constexpr (MODE == 2) { if (T - 7 < cx.nc2) patch_issue_skip<BN, NW>(cx, T - 7, c); }
     if constexpr (T == 0 && MODE == 0) patch_issue_patch<BN, NW>(cx, c + 1, (c + 1) & 1);
-    bf16x8 fa[4];
-    patch_read_a<BN, NW, T>(cx, fa, c);
+    constexpr int CUR = T & 1, NXT = 1 - CUR;
+    // (not in the chunk that is followed by the appended operand: with that variant's extra state the second set spills)
+    // Only the 8-wave tile (one workgroup per CU: its waves run in lockstep between barriers) gains from this -- 3...7 % per launch;
+    // with two 4-wave workgroups per CU the other workgroup's waves already fill the read phase (A/B: -0.3 % end to end).
+    constexpr bool PF = NW == 8 && MODE != 2;                   // this chunk prefetches
+    constexpr bool PRE = PF && (T < 8 || MODE == 0);            // ... and a conv tap follows this one
+    if constexpr (!PF && T > 0) patch_read_a<BN, NW, T>(cx, fa[CUR], c);
+    if constexpr (T == 0) {
+        if (!have || NW != 8) {                                              // very first tap of the workgroup: nothing was prefetched
+            patch_read_a<BN, NW, 0>(cx, fa[0], c);
+        } else {                                                  // prefetched by tap 8 of the previous chunk into the odd half
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = fa[1][i];
+        }
+    }
+    // fragment addresses of the next tap (recomputed per tap on purpose: see patch_read_a)
+    unsigned na[4];
+    if constexpr (PRE) {
+        constexpr int TN_ = T < 8 ? T + 1 : 0;
+        int pw = cx.PW;
+        asm volatile("" : "+s"(pw));
+        const int shift = (TN_ / 3 - 1) * pw + (TN_ % 3 - 1);
+        const int cn = T < 8 ? c : c + 1;
+        const unsigned pbase = cx.lds0 + (cn & 1) * P::PBUF + (cx.kg << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int sb = cx.sbase[i];
+            asm volatile("" : "+v"(sb));
+            const int sl = sb + shift;
+            na[i] = (pbase + (sl << 6)) ^ ((sl & 4) << 3);
+        }
+    }
     unsigned sbb = cx.b_frag;
     asm volatile("" : "+v"(sbb));                               // see patch_read_a: keep the fragment addresses from being hoisted
     sbb += (T % 3) * P::BSTAGE;
@@ -1073,24 +1120,28 @@ __device__ __forceinline__ void patch_tap(const PatchCtx<BN, NW>& cx, f32x4 (&ac
     fb[0] = lds_read128(sbb);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        if (j + 1 < TN) {
-            fb[(j + 1) & 1] = lds_read128(sbb + (j + 1) * 16 * 64);
-            asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        // LDS reads return in order: after issuing this group's reads, everything up to fb[j] must be back; what may stay
+        // outstanding is this group's own reads plus the previous group's prefetch read (issued after fb[j])
+        const bool pf = PRE && j < 4;                            // this group carries prefetch read j
+        if (j + 1 < TN) fb[(j + 1) & 1] = lds_read128(sbb + (j + 1) * 16 * 64);
+        if (pf) fa[NXT][j < 4 ? j : 0] = lds_read128(na[j < 4 ? j : 0]);
+        const int outstanding = (j + 1 < TN ? 1 : 0) + (pf ? 1 : 0) + ((PRE && j >= 1 && j <= 4) ? 1 : 0);
+        if (outstanding == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (outstanding == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (outstanding == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[CUR][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <int BN, int NW, int MODE>
-__device__ __forceinline__ void patch_chunk(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], int c) {
-    patch_tap<BN, NW, 0, MODE>(cx, acc, c); patch_tap<BN, NW, 1, MODE>(cx, acc, c); patch_tap<BN, NW, 2, MODE>(cx, acc, c);
-    patch_tap<BN, NW, 3, MODE>(cx, acc, c); patch_tap<BN, NW, 4, MODE>(cx, acc, c); patch_tap<BN, NW, 5, MODE>(cx, acc, c);
-    patch_tap<BN, NW, 6, MODE>(cx, acc, c); patch_tap<BN, NW, 7, MODE>(cx, acc, c); patch_tap<BN, NW, 8, MODE>(cx, acc, c);
+__device__ __forceinline__ void patch_chunk(const PatchCtx<BN, NW>& cx, f32x4 (&acc)[4][BN / 32], bf16x8 (&fa)[2][4], bool have, int c) {
+    patch_tap<BN, NW, 0, MODE>(cx, acc, fa, have, c); patch_tap<BN, NW, 1, MODE>(cx, acc, fa, true, c); patch_tap<BN, NW, 2, MODE>(cx, acc, fa, true, c);
+    patch_tap<BN, NW, 3, MODE>(cx, acc, fa, true, c); patch_tap<BN, NW, 4, MODE>(cx, acc, fa, true, c); patch_tap<BN, NW, 5, MODE>(cx, acc, fa, true, c);
+    patch_tap<BN, NW, 6, MODE>(cx, acc, fa, true, c); patch_tap<BN, NW, 7, MODE>(cx, acc, fa, true, c); patch_tap<BN, NW, 8, MODE>(cx, acc, fa, true, c);
 }
 
 // the appended dense operand: one k-tile per 32-channel chunk, weight stage s % 3, A2 tile slot s % 4, fetch distance 2
@@ -1145,15 +1196,20 @@ __device__ __forceinline__ void patch_static_loop(const PatchCtx<BN, NW>& cx, f3
     patch_issue_patch<BN, NW>(cx, c_begin, c_begin & 1);
     patch_issue_b<BN, NW>(cx, c_begin, 0, 0);
     patch_issue_b<BN, NW>(cx, c_begin, 1, 1);
-    for (int c = c_begin; c + 1 < nch; ++c) patch_chunk<BN, NW, 0>(cx, acc, c);
+    bf16x8 fa[2][4];
+    bool have = false;
+    for (int c = c_begin; c + 1 < nch; ++c) {
+        patch_chunk<BN, NW, 0>(cx, acc, fa, have, c);
+        have = true;
+    }
     if constexpr (HAS2) {
         if (cx.nc2 > 0) {
-            patch_chunk<BN, NW, 2>(cx, acc, nch - 1);
+            patch_chunk<BN, NW, 2>(cx, acc, fa, have, nch - 1);
             patch_skip_loop<BN, NW>(cx, acc, nch - 1);
             return;
         }
     }
-    patch_chunk<BN, NW, 1>(cx, acc, nch - 1);
+    patch_chunk<BN, NW, 1>(cx, acc, fa, have, nch - 1);
 }
 
 // HAS2: instantiated separately for convolutions with an appended operand, so that the plain kernel does not carry its state
@@ -1168,11 +1224,8 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
 
     const int tiles_n = (d.N + BN - 1) / BN;
     const int nb = (d.M / BM) * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+    const int kz = xcd_item(nb, tiles_n) / nb;                  // (k-slice, tile) work items, XCD-contiguous: see igemm_kernel
+    const int bid = xcd_item(nb, tiles_n) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -1212,7 +1265,6 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
     const int cin = d.Cin;
     const int nc1 = cin >> 5, nc2 = HAS2 ? d.K2 >> 5 : 0, nch_all = nc1 + nc2;
     // split-K: gridDim.z slices of the 32-channel chunk sequence (a conv chunk = 9 k-tiles, an A2 chunk = 1)
-    const int kz = blockIdx.z;
     const int c_begin = (int)((long)nch_all * kz / (int)gridDim.z), nch = (int)((long)nch_all * (kz + 1) / (int)gridDim.z);
     const int ncv = (nch < nc1 ? nch : nc1) - (c_begin < nc1 ? c_begin : nc1);        // conv chunks in [c_begin, nch)
     const int S = 9 * ncv + (nch - c_begin - ncv);
