@@ -515,6 +515,26 @@ def test_fused_geglu_projection(nsplit, M, C):
     assert _relerr(o.to_f32().cpu(), h * F.gelu(g)) < _tol(nsplit)
 
 
+@pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 11, 12, 14, 17])
+def test_fused_geglu_projection_every_tile(nsplit, tile):
+    """The GEGLU epilogue has two forms: tiles with four-fold n-tile counts (128 / 256 columns) deal the packed rows so that a
+    lane owns value and gate of 8 consecutive outputs (direct stores); the others keep the [a | gate] order and go through LDS.
+    M is ragged and 2H = 1344 is a multiple of 64 but of no tile width, so every tile masks rows AND columns."""
+    if nsplit == 2 and tile >= 11:
+        pytest.skip("BK = 64 tiles are bf16-mode tiles")
+    M, C, H = 300, 128, 672
+    x, w, bias = _t("gx", M, C), _t("gw", 2 * H, C) / np.sqrt(C), _t("gb", 2 * H)
+    b = _builder(nsplit, {"p.weight": w.cuda(), "p.bias": bias.cuda()})
+    xd = x.cuda()
+    a = b.pack(xd.data_ptr(), 1, M, C, 0, C)
+    o = b.linear_geglu(a, "p")
+    b.prog.ops[-1][1].tile = tile
+    _run(b)
+    h, g = (x @ w.t() + bias).chunk(2, dim=-1)
+    assert _relerr(o.to_f32().cpu(), h * F.gelu(g)) < _tol(nsplit)
+
+
 def test_pack_relayout_roundtrip():
     B, C, H, W = 2, 6, 8, 8
     x = _t("px", B, C, H, W)
