@@ -516,6 +516,33 @@ def test_fused_geglu_projection(nsplit, M, C):
 
 
 @pytest.mark.parametrize("nsplit", [2, 1])
+@pytest.mark.parametrize("out", ["f32", "op"])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17])
+def test_gemm_direct_epilogue_every_tile(nsplit, out, tile):
+    """The store-from-registers epilogue (transposed accumulators, permuted weight rows): alpha, bias and a stream-dtype residual,
+    stream or operand output, on every tile variant; M = 300 and N = 352 (a multiple of 32 and of no tile width) mask rows and
+    whole 8-column groups; K = 320 gives the BK = 64 pipelined loop an odd number of k-steps per parity (5 stages)."""
+    if tile in (7, 8) and nsplit == 2 or tile >= 11 and nsplit == 2:
+        pytest.skip("8-wave and BK = 64 tiles are bf16-mode tiles")
+    M, N, K = 300, 352, 320
+    a, w, bias, res = _t("da", M, K), _t("dw", N, K) / np.sqrt(K), _t("db", N), _t("dr", M, N)
+    b = _builder(nsplit, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+    ad = a.cuda()
+    a_op = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+    kw = {}
+    if out == "f32":
+        r = b.f32(M, N)
+        r.view().copy_(res.cuda())
+        kw["residual"] = r
+    o = b.linear(a_op, "w", alpha=0.75, out=out, **kw)
+    b.prog.ops[-1][1].tile = tile
+    _run(b)
+    ref = 0.75 * (a @ w.t()) + bias + (res if out == "f32" else 0)
+    got = o.view().float().cpu() if out == "f32" else o.to_f32().cpu()[:, :N]
+    assert _relerr(got, ref) < _tol(nsplit)
+
+
+@pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 11, 12, 14, 17])
 def test_fused_geglu_projection_every_tile(nsplit, tile):
     """The GEGLU epilogue has two forms: tiles with four-fold n-tile counts (128 / 256 columns) deal the packed rows so that a
