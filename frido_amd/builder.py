@@ -18,6 +18,9 @@ ATTN_FLASH = os.environ.get("FRIDO_ATTN_FLASH", "1") != "0"       # flash-style 
 # below this many keys the score matrix is small and the batched GEMM -> softmax -> GEMM chain fills the chip better than
 # one workgroup per 64 queries (measured at B = 16: 256 keys x d = 576: 37 us vs 49 us; 1024 keys x d = 384: 102 vs 82 us)
 ATTN_FLASH_MIN_KEYS = int(os.environ.get("FRIDO_ATTN_FLASH_MIN_KEYS", "512"))
+# SHORT key sequences (cross-attention: 26 / 92 / 1 tokens) on planes with at least this many queries per sample also take the
+# flash kernel (one 32-key tile, no cross-wave score exchange) instead of the 16-query short-key kernel; 0 = never
+ATTN_FLASH_SHORT_NQ = int(os.environ.get("FRIDO_ATTN_FLASH_SHORT_NQ", "0"))
 
 
 class Builder:
@@ -400,8 +403,10 @@ class Builder:
         Np = rup(Nk, 32)
         aligned = ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0
         small = Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and aligned
-        flash = (not small and ATTN_FLASH and aligned and _lib.lib().frido_attn_flash_supported(d)
-                 and (Nk >= ATTN_FLASH_MIN_KEYS or Nk > 4096))
+        flash_ok = ATTN_FLASH and aligned and _lib.lib().frido_attn_flash_supported(d)
+        short_flash = small and flash_ok and ATTN_FLASH_SHORT_NQ > 0 and Nq >= ATTN_FLASH_SHORT_NQ
+        small = small and not short_flash
+        flash = not small and flash_ok and (Nk >= ATTN_FLASH_MIN_KEYS or Nk > 4096 or short_flash)
         if small or flash:
             # one launch, scores stay on chip: the short-key kernel (cross-attention, 8x8 planes) or the flash-style kernel
             kind = "FRIDO_OP_ATTN_SMALL" if small else "FRIDO_OP_ATTN_FLASH"
