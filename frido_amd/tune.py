@@ -20,6 +20,10 @@ _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
 K64_ALL = os.environ.get("FRIDO_TUNE_K64_ALL", "1") != "0"           # try the BK = 64 tiles on every shape, not only small M
 BIG_SPLITK = os.environ.get("FRIDO_TUNE_BIG_SPLITK", "1") != "0"      # also try the 8-wave 256-row tiles under split-K
+# Time every candidate with COLD weights: in the sampler a GEMM's weights come from HBM (0.8 GB of them stream through the
+# 256 MB MALL per forward) while its activations were just written; timed back to back on one buffer the weights sit in L2 /
+# MALL instead.  With this on, consecutive repetitions read different copies of the weight operand out of a >= 320 MB ring.
+COLD_B = os.environ.get("FRIDO_TUNE_COLD_B", "0") != "0"
 CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
 _dirty = False
 
@@ -88,6 +92,9 @@ def workspace(device, nbytes, tag=""):
     return t.data_ptr()
 
 
+_rot = [0]
+
+
 def best_tile(st, device, stream):
     """st: a filled FridoGemm ctypes struct (pointers are ignored: scratch buffers are substituted).
     Returns (tile, splitk)."""
@@ -109,7 +116,10 @@ def best_tile(st, device, stream):
     b_elems = st.batch * max(st.b_bs, st.b_bs2, st.N * st.ldb) if (st.b_bs or st.b_bs2) else st.N * st.ldb
     a_elems, b_elems = (a_elems + 7) // 8 * 8, (b_elems + 7) // 8 * 8
     t.A, t.a_lo = _buf("A", a_elems * 2 * ns, device), a_elems
-    t.B, t.b_lo = _buf("B", b_elems * 2 * ns, device), b_elems
+    b_bytes = b_elems * 2 * ns
+    nrot = max(1, min(64, -(-(320 << 20) // b_bytes))) if COLD_B and st.batch == 1 else 1      # batched B operands are activations
+    b_base = _buf("B", b_bytes * nrot, device)
+    t.B, t.b_lo = b_base, b_elems
     if st.K2:
         a2 = (st.M * st.lda2 + 7) // 8 * 8
         t.A2, t.a2_lo = _buf("A2", a2 * 2 * ns, device), a2
@@ -153,7 +163,17 @@ def best_tile(st, device, stream):
             if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue
             t.tile = tile
-            arr = _lib.pack_ops([(kind, t)] * (reps + 1))
+            if nrot > 1:
+                ops = []
+                for _ in range(reps + 1):
+                    u = G()
+                    C.memmove(C.addressof(u), C.addressof(t), C.sizeof(G))
+                    u.B = b_base + (_rot[0] % nrot) * b_bytes
+                    _rot[0] += 1
+                    ops.append((kind, u))
+                arr = _lib.pack_ops(ops)
+            else:
+                arr = _lib.pack_ops([(kind, t)] * (reps + 1))
             ms = (C.c_float * (reps + 1))()
             rc = L.frido_run_timed(C.addressof(arr), reps + 1, stream, ms)
             if rc != 0:
