@@ -17,7 +17,11 @@
 //  * nsplit == 2 ("bf16x3"): operands carry a second bf16 plane with the rounding residual and each
 //    tile product is hi*hi + hi*lo + lo*hi (fp32 accumulate) — ~2^-17 relative error at 3 MFMAs;
 //  * fused epilogue: alpha, bias[n], per-row bias, per-row-group vector (timestep embedding), ReLU/SiLU,
-//    residual, f32 and/or operand (bf16 hi/lo) output.
+//    residual, f32 and/or operand (bf16 hi/lo) output.  Every MFMA takes the WEIGHT fragment as its first operand, so an
+//    accumulator tile is C^T (a lane owns consecutive channels of one pixel) and the hot epilogues store straight from
+//    registers -- see tile_epilogue;
+//  * the BK = 64 bf16 tiles run a software-pipelined loop (fragments of the next k-step prefetched under the MFMAs);
+//  * split-K work items (k-slice, tile) are dealt to the XCDs in contiguous ranges (xcd_item).
 #include "common.h"
 #include <atomic>
 #include <type_traits>
@@ -42,7 +46,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // dispatch-order id of this workgroup within its batch slice -> work item (see igemm_kernel): XCD x = id & 7 takes items
 // [start(x), start(x) + count(x)) of the nb * gridDim.z items
-__device__ __forceinline__ int xcd_item(int nb, int) {
+__device__ __forceinline__ int xcd_item(int nb) {
     const int total = nb * (int)gridDim.z;
     const int id = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
     const int q = total >> 3, r = total & 7, xcd = id & 7, loc = id >> 3;
@@ -92,10 +96,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int OFF>
-__device__ __forceinline__ void lds_write32(unsigned addr, float v) {
-    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
 template <int OFF>
 __device__ __forceinline__ float4 lds_read128f(unsigned addr) {
     float4 v;
@@ -585,8 +585,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     // split-K an XCD works on ONE k-slice (or a few), so its L2 holds that slice of the weights once.  Before (k-slice =
     // blockIdx.z, every XCD walked all slices): the 8x8-plane convs (M = 1024, split 8) fetched 72 MB per launch from
     // MALL / HBM for 18.6 MB of operands (tools/_pmc_smallm.sh).
-    const int kz = xcd_item(nb, tiles_n) / nb;
-    const int bid = xcd_item(nb, tiles_n) - kz * nb;
+    const int kz = xcd_item(nb) / nb;
+    const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     // batch index, optionally two-level (outer x inner, e.g. image x head)
@@ -1224,8 +1224,8 @@ __global__ __launch_bounds__((NW * 64), (NW == 8 ? 1 : 2)) void conv3x3_patch_ke
 
     const int tiles_n = (d.N + BN - 1) / BN;
     const int nb = (d.M / BM) * tiles_n;
-    const int kz = xcd_item(nb, tiles_n) / nb;                  // (k-slice, tile) work items, XCD-contiguous: see igemm_kernel
-    const int bid = xcd_item(nb, tiles_n) - kz * nb;
+    const int kz = xcd_item(nb) / nb;                  // (k-slice, tile) work items, XCD-contiguous: see igemm_kernel
+    const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
