@@ -542,6 +542,22 @@ def test_gemm_direct_epilogue_every_tile(nsplit, out, tile):
     assert _relerr(got, ref) < _tol(nsplit)
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 448])
+@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 16, 17])
+def test_pipelined_loop_short_k(tile, K):
+    """The software-pipelined BK = 64 loop at 1, 2, 3 and 7 ring stages (prologue only / no refill / first refill / wrap-around of
+    the 3-4 slot ring), bf16 mode."""
+    M, N = 272, 224
+    a, w, bias = _t("sa", M, K), _t("sw", N, K) / np.sqrt(K), _t("sb", N)
+    b = _builder(1, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+    ad = a.cuda()
+    a_op = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+    o = b.linear(a_op, "w", out="op")
+    b.prog.ops[-1][1].tile = tile
+    _run(b)
+    assert _relerr(o.to_f32().cpu(), a @ w.t() + bias) < _tol(1)
+
+
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 11, 12, 14, 17])
 def test_fused_geglu_projection_every_tile(nsplit, tile):
