@@ -1,3 +1,4 @@
+# per-tile launch times (tools/gemm_bench.py) of the 64^2 / 32^2 convs and the 16384-row dense GEMMs: before / after record of an epilogue or main-loop change
 for cin in 64 192 576; do
   echo "== conv 16x64x64 $cin->192"; python tools/gemm_bench.py conv 16 64 64 $cin 192 1 9,10,2 2>&1 | grep -E "tile|Error"
 done

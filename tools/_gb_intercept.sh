@@ -1,3 +1,4 @@
+# K sweep with / without epilogue (NOEPI=0/1): per-launch fixed cost, epilogue cost and main-loop rate -> profiles/r02_gemm_k_sweep.txt
 for cin in 32 64 128 192 384 576; do
   for ne in 0 1; do
     echo "== conv 16x64x64 $cin->192 NOEPI=$ne"; NOEPI=$ne python tools/gemm_bench.py conv 16 64 64 $cin 192 1 9,2 2>&1 | grep -E "tile|Error"

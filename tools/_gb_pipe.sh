@@ -1,3 +1,4 @@
+# per-tile record that decided where the software-pipelined loop is used -> profiles/r02_pipelined_loop_per_tile.txt
 bash tools/_gb_direct.sh
 for sk in 4 8; do
   echo "== conv 16x8x8 960->960 splitk=$sk"; SPLITK=$sk python tools/gemm_bench.py conv 16 8 8 960 960 1 1,2,7,8,11,12,17 2>&1 | grep -E "tile|Error"

@@ -1,3 +1,4 @@
+# tile x split-K sweep on the small-M conv shapes (8x8 and 16x16 planes)
 for sk in 1 2 4 8 12 16; do
   echo "== conv 16x8x8 960->960 splitk=$sk"; SPLITK=$sk python tools/gemm_bench.py conv 16 8 8 960 960 1 1,2,4,6,7,8,9,10,11,12,17 2>&1 | grep -E "tile|Error"
 done
