@@ -26,6 +26,13 @@
 #include <atomic>
 #include <type_traits>
 
+// Timing ablations of the bf16x3 main loop (tools/build_ablate.sh builds SEPARATE libraries with -DFRIDO_ABLATE=<mask>; the shipped
+// library is built with 0 and contains none of this): 1 = no DMA refills inside the loop, 2 = no fragment reads, 4 = no barriers /
+// vmcnt waits, 8 = no MFMAs.  Results are garbage; only the launch time means anything.
+#ifndef FRIDO_ABLATE
+#define FRIDO_ABLATE 0
+#endif
+
 namespace {
 
 __device__ uint4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
@@ -68,7 +75,10 @@ struct Geo {
     // many-workgroup shapes occupancy hides latency better than bytes in flight (measured: 8 stages = -20 % on
     // 16384x384x384).  8-wave tiles own the CU, so they take what fits.
     static constexpr int D8 = 147456 / STAGE > 6 ? 6 : 147456 / STAGE;
-    static constexpr int D = NW == 8 ? D8 : ((4 * STAGE <= 98304 && NS == 1) ? 4 : 3);
+    // bf16x3 (NS == 2) runs the software-pipelined virtual-k-step loop, in which every ring slot carries loads: two
+    // 4-wave workgroups per CU (<= 80 KiB each) with 2-4 stages, or one 8-wave workgroup with what fits
+    static constexpr int DX = 81920 / STAGE < 2 ? 2 : (81920 / STAGE > 4 ? 4 : 81920 / STAGE);
+    static constexpr int D = NW == 8 ? (D8 < 2 ? 2 : D8) : (NS == 2 ? DX : ((4 * STAGE <= 98304) ? 4 : 3));
     static constexpr int SLABS = NW * 16 * (BN / 2 + 4) * 4;   // epilogue transpose slabs (one per wave)
     // + the bf16 residual sub-tile of every wave, DMA'd into the idle ring at the start of the epilogue (bf16 mode)
     static constexpr bool RSTAGE = NS == 1 && SLABS + BM * BN * 2 <= 163840;
@@ -601,8 +611,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     // ---- LDS-DMA assignments: wave w moves chunks w, w+4, ... ; lane l of a chunk lands at row l>>2, physical
     //      slot l&3, i.e. it must FETCH logical slot (l&3) ^ swz(row) ----
     // BK = 32: 64-B rows, 4 slots, slot q of row r at q ^ ((4 - (r>>2)) & 3);  BK = 64: 128-B rows, 8 slots, q ^ ((r>>1) & 7)
-    const int lrow = BK == 32 ? lane >> 2 : lane >> 3;
-    const int lq = BK == 32 ? (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3)
+    // (ablation 64, dense bf16x3 timing only: a piece = 8 rows x 128 contiguous bytes of a plane-interleaved operand; the "lo" piece
+    //  covers the chunk's rows 8..15 -- same instruction count and bytes as the shipped 16 rows x 64 B pieces, full 128-B lines)
+    constexpr bool AB64 = (FRIDO_ABLATE & 64) && NS == 2 && !CONV;
+    const int lrow = (BK == 32 && !AB64) ? lane >> 2 : lane >> 3;
+    const int lq = AB64 ? (lane & 7) : BK == 32 ? (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3)
                             : (lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7);
     // conv: element offset of tap (0,0) of this row's receptive field + a bit mask of the taps that fall inside
     // the (logical) input; with resampling folded in (up/dn shifts) the per-tap offsets are tabulated instead
@@ -633,7 +646,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             a_off[j] = ((int64_t)(b * d.Hs + oy * d.stride - pady) * d.Ws + (ox * d.stride - padx)) * d.Cin + lq * 8;
         } else {
             m = m < d.M ? m : d.M - 1;      // rows past M are clamped (their outputs are masked)
-            a_off[j] = (int64_t)m * d.lda + lq * 8;
+            a_off[j] = (int64_t)m * d.lda * ((FRIDO_ABLATE & 16) ? 2 : 1) + lq * 8;
         }
     }
     int64_t a2_off[JA];
@@ -651,7 +664,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         const int row = (wave + NW * j) * CHR + lrow;
         int n = n0 + (d.geglu ? row : chan_of_pos(row));      // LDS row `row` holds channel chan_of_pos(row): see tile_epilogue
         n = n < d.N ? n : d.N - 1;
-        b_off[j] = (int64_t)n * d.ldb + lq * 8;
+        b_off[j] = (int64_t)n * d.ldb * ((FRIDO_ABLATE & 16) && !CONV ? 2 : 1) + lq * 8;
     }
 
     // k-tile range of this workgroup (split-K: gridDim.z slices)
@@ -663,7 +676,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     // keep the zero page's address in SGPRs (otherwise hipcc re-loads it from the GOT inside the k-loop)
     unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
     asm volatile("" : "+s"(zero_addr));
-    const int64_t b_lo = d.b_lo;
+    const int64_t b_lo = AB64 ? (int64_t)16 * d.ldb : (FRIDO_ABLATE & 16) && !CONV ? 32 : d.b_lo;
+    constexpr int KADV = (FRIDO_ABLATE & 16) && !CONV ? 2 * BK : BK;      // elements a dense source pointer advances per k-tile
 
     // ---- incremental source pointers.  Inside one SEGMENT of the k-walk (the channel chunks of one conv tap, the whole K of
     //      a dense operand, the appended A2 range) every piece just advances by BK elements per k-tile; the per-piece
@@ -673,10 +687,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     int astep[JA];                      // BK, or 0 for a piece parked on the zero page
     const frido_bf16* bptr[JB];
 #pragma unroll
-    for (int j = 0; j < JB; ++j) bptr[j] = Bb + b_off[j] + (int64_t)kt0 * BK;
+    for (int j = 0; j < JB; ++j) bptr[j] = Bb + b_off[j] + (int64_t)kt0 * KADV;
     int ktn = kt0;                      // next k-tile to issue
     int seg_left = 0;                   // k-tiles left in the current segment
     int64_t alo_cur = d.a_lo;           // hi -> lo plane distance of the operand the segment reads
+    int rt_tap = -1, rt_ky = 0, rt_kx = 0;      // conv k-walk state: tap of the current segment (-1: none yet) and its (ky, kx)
     auto retap = [&]() {
         if (ktn >= nk1) {               // appended dense operand (fused 1x1 skip conv): runs to the end of K
 #pragma unroll
@@ -687,9 +702,23 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             alo_cur = d.a2_lo;
             seg_left = 1 << 30;
         } else if (CONV) {
+            // k-tile ktn -> (tap, first channel kc); a segment = the channel chunks of one tap.  After the first call a segment ends
+            // exactly at a tap boundary, so the walk just steps to the next tap: no divisions on the hot path (the general form
+            // below was ~250 instructions between the k-tile's barrier and its first DMA piece, once per tap).
             const int cpt = cin / BK;
-            const int tap = ktn / cpt, kc = (ktn - tap * cpt) * BK;
-            const int ky = tap / kw, kx = tap - ky * kw;
+            int tap, kc;
+            if (rt_tap >= 0) {
+                tap = rt_tap + 1;
+                kc = 0;
+            } else {
+                tap = ktn / cpt;
+                kc = (ktn - tap * cpt) * BK;
+                rt_ky = tap / kw;
+                rt_kx = tap - rt_ky * kw - 1;
+            }
+            rt_tap = tap;
+            if (++rt_kx == kw) { rt_kx = 0; ++rt_ky; }
+            const int ky = rt_ky, kx = rt_kx;
 #pragma unroll
             for (int j = 0; j < JA; ++j) {
                 const bool ok = (a_mask[j] >> tap) & 1u;
@@ -709,9 +738,10 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         } else {
 #pragma unroll
             for (int j = 0; j < JA; ++j) {
-                aptr[j] = Ab + a_off[j] + (int64_t)ktn * BK;
-                astep[j] = BK;
+                aptr[j] = Ab + a_off[j] + (int64_t)ktn * KADV;
+                astep[j] = KADV;
             }
+            if constexpr ((FRIDO_ABLATE & 16) && !CONV) alo_cur = AB64 ? (int64_t)16 * d.lda : 32;
             seg_left = nk1 - ktn;
         }
     };
@@ -748,7 +778,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
             if (NS == 2)
                 __builtin_amdgcn_global_load_lds((gptr_t)(bptr[j] + b_lo), (lptr_t)(sb + PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
-            bptr[j] += BK;
+            bptr[j] += KADV;
         }
         ++ktn;
         --seg_left;
@@ -862,7 +892,147 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         } else if (st + 1 == nsteps) {
             step(std::integral_constant<int, 0>{}, F_{}, st / KS, st % KS);
         }
+    } else if constexpr (NS == 2 && BN / 2 / 16 <= 4) {
+        // ---- bf16x3 main loop: software-pipelined over VIRTUAL k-steps (r03).  A stage holds the hi and lo planes of one 32-deep
+        //      k-tile (= the LDS bytes of one BK = 64 bf16 stage); its product hi*hi + hi*lo + lo*hi is walked as three virtual
+        //      k-steps, each TM x TN MFMAs on ONE pixel-fragment set and ONE weight-fragment set:
+        //          v0: A_hi x B_hi   (meanwhile B_lo is read into the idle weight set)
+        //          v1: A_hi x B_lo   (meanwhile A_lo is read into the idle pixel set)
+        //          v2: A_lo x B_hi   (meanwhile the NEXT stage's A_hi / B_hi are read into the two sets v1 used)
+        //      so two register sets per operand (the bf16 BK = 64 budget) carry three MFMA rounds per 2 (TM + TN) fragment reads,
+        //      and the matrix pipe has TM x TN MFMAs queued behind every read / DMA / barrier phase.  The hi weights alternate
+        //      between fb[0] and fb[1] from stage to stage (Q), so the loop is unrolled by two stages.  Ring protocol as in the
+        //      bf16 pipelined loop: the barrier sits at the head of v2 (every wave then holds the whole stage in registers: its
+        //      slot is refilled at once, all D slots carry loads); with D >= 3 the refill's DMA pieces are dealt over the MFMA
+        //      groups of v2 and the next stage's v0 / v1, with D = 2 they go out in v2 (the stage must land one k-tile later).
+        //      The old loop (one barrier, 2 (TM + TN) reads, then 3 TM TN MFMAs per k-tile, D = 3: ONE 4-wave workgroup per CU) left the
+        //      pipe idle through every read phase: 270-300 TF/s (algorithmic) on the 64x64-plane convs.
+        static_assert(BK == 32, "bf16x3 tiles: BK = 32 (two planes of 32 = the LDS stage of one plane of 64)");
+        constexpr int NPC = (JA + JB) * 2;                           // DMA pieces per thread per stage (= G::LPT)
+        constexpr bool SPREAD = D >= 3;
+        constexpr int NG = SPREAD ? 3 * TN : TN;                     // MFMA groups one refill is dealt over
+        static_assert(D <= 6 && (D - 1) * G::LPT < 64, "vmcnt immediate");
+        auto wait_younger = [&](int younger) {                       // stages issued after the one waited for (loads retire in order)
+            switch (younger) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<(D > 1 ? 1 : 0) * G::LPT>(); break;
+                case 2: wait_vmcnt<(D > 2 ? 2 : 0) * G::LPT>(); break;
+                case 3: wait_vmcnt<(D > 3 ? 3 : 0) * G::LPT>(); break;
+                case 4: wait_vmcnt<(D > 4 ? 4 : 0) * G::LPT>(); break;
+                default: wait_vmcnt<(D > 5 ? 5 : 0) * G::LPT>(); break;
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < nk) issue(s);
+        bf16x8 fa[2][TM], fb[2][TN];                                 // fa[0] = A_hi, fa[1] = A_lo;  fb[Q] = B_hi, fb[1 - Q] = B_lo
+        const unsigned afr = a_frag + fslot0, bfr = b_frag + fslot0;
+        if (nk > 0) {
+            wait_younger(nk - 1 < D - 1 ? nk - 1 : D - 1);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = lds_read128(bfr + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = lds_read128(afr + i * 16 * ROWB);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        int buf = 0;                                                 // ring slot of the stage being multiplied
+        bool dma = false;                                            // a refill is in progress ...
+        int dbuf = 0;                                                // ... into this slot
+        // DMA piece pi of the refill in progress: (A chunk 0 hi, lo), (A chunk 1 hi, lo), ..., (B chunk 0 hi, lo), ...
+        auto piece = [&](auto pc) {
+            constexpr int pi = decltype(pc)::value, idx = pi >> 1, pl = pi & 1;
+            unsigned char* sb = smem + dbuf * STAGE + pl * PLANE + wave * 1024;
+            if constexpr (idx < JA) {
+                const frido_bf16* src = (pl && astep[idx]) ? aptr[idx] + alo_cur : aptr[idx];
+                if constexpr (FRIDO_ABLATE & 32) src = reinterpret_cast<const frido_bf16*>(zero_addr) + (lane & 3) * 8;   // same 64 bytes for every piece
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + idx * (NW * 1024)), 16, 0, 0);
+                if constexpr (pl == 1) aptr[idx] += astep[idx];
+            } else {
+                constexpr int j = idx - JA;
+                const frido_bf16* srcb = bptr[j] + (pl ? b_lo : 0);
+                if constexpr (FRIDO_ABLATE & 32) srcb = reinterpret_cast<const frido_bf16*>(zero_addr) + (lane & 3) * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+                if constexpr (pl == 1) bptr[j] += KADV;
+            }
+        };
+        auto vstep = [&](auto vc, auto qc, auto prec, int kt) {
+            constexpr int V = decltype(vc)::value, Q = decltype(qc)::value;
+            constexpr bool PRE = decltype(prec)::value;             // v2 only: a next stage exists
+            constexpr int BS = V == 1 ? 1 - Q : Q, AS = V == 2 ? 1 : 0;
+            unsigned ra = afr + buf * STAGE + PLANE, rb = bfr + buf * STAGE + PLANE;     // the lo planes of this stage (v0, v1)
+            int nbuf = buf;
+            if constexpr (V == 2) {
+                if constexpr (PRE) {
+                    // stage kt + 1 must have landed; past this barrier every wave holds stage kt in registers: its slot is free
+                    if constexpr (!(FRIDO_ABLATE & 4)) {
+                        if (kt + D - 1 < nk) wait_vmcnt<(D - 2) * G::LPT>();
+                        else wait_younger(nk - kt - 2);
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    nbuf = buf + 1 == D ? 0 : buf + 1;
+                    ra = afr + nbuf * STAGE;
+                    rb = bfr + nbuf * STAGE;
+                    dma = kt + D < nk && !(FRIDO_ABLATE & 1);
+                    dbuf = buf;
+                    if (dma) issue_begin();
+                } else {
+                    dma = false;
+                }
+            }
+            constexpr int NR = V == 0 ? TN : (V == 1 ? TM : (PRE ? TM + TN : 0));      // fragment reads issued under this step
+            // ... all of them under its FIRST groups (pixel fragments first: the next step needs every one of them at once, the weight
+            // fragments one group at a time), so that the lgkmcnt(0) at the end of the step finds them landed
+            constexpr int RG = TN > 2 ? TN - 2 : 1;
+            static_for<0, TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (!(FRIDO_ABLATE & 2) && j < RG) static_for<j * NR / RG, (j + 1) * NR / RG>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (V == 0) fb[1 - Q][r] = lds_read128(rb + r * 16 * ROWB);
+                    else if constexpr (V == 1) fa[1][r] = lds_read128(ra + r * 16 * ROWB);
+                    else if constexpr (r < TM) fa[0][r] = lds_read128(ra + r * 16 * ROWB);
+                    else fb[1 - Q][r - TM] = lds_read128(rb + (r - TM) * 16 * ROWB);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(FRIDO_ABLATE & 8)) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[BS][j], fa[AS][i], acc[i][j], 0, 0, 0);   // weights first: C^T tiles
+                } else {
+                    asm volatile("" :: "v"(fb[BS][j]), "v"(fa[AS][0]), "v"(fa[AS][TM - 1]));      // keep the fragment reads alive
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int g = V == 2 ? j : (V == 0 ? TN + j : 2 * TN + j);          // group index within the refill begun at v2
+                if constexpr (g < NG) {
+                    if (dma) {
+                        static_for<g * NPC / NG, (g + 1) * NPC / NG>([&](auto pc) { piece(pc); });
+                        if constexpr (g == NG - 1) issue_end();
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (NR > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (V == 2) buf = nbuf;
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            vstep(I0{}, I0{}, T_{}, kt); vstep(I1{}, I0{}, T_{}, kt); vstep(I2{}, I0{}, T_{}, kt);
+            vstep(I0{}, I1{}, T_{}, kt + 1); vstep(I1{}, I1{}, T_{}, kt + 1); vstep(I2{}, I1{}, T_{}, kt + 1);
+        }
+        if (kt + 2 == nk) {
+            vstep(I0{}, I0{}, T_{}, kt); vstep(I1{}, I0{}, T_{}, kt); vstep(I2{}, I0{}, T_{}, kt);
+            vstep(I0{}, I1{}, T_{}, kt + 1); vstep(I1{}, I1{}, T_{}, kt + 1); vstep(I2{}, I1{}, F_{}, kt + 1);
+        } else if (kt + 1 == nk) {
+            vstep(I0{}, I0{}, T_{}, kt); vstep(I1{}, I0{}, T_{}, kt); vstep(I2{}, I0{}, F_{}, kt);
+        }
     } else {
+    // ---- plain loop (bf16 BK = 32 tiles; bf16x3 tiles with six n-tiles per wave, whose second fragment sets would spill: those run
+    //      as TWO 4-wave workgroups per CU on a 2-slot ring, the other workgroup's MFMAs covering this one's read phase) ----
     // ---- prologue: fill D-1 stages ----
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
@@ -1590,8 +1760,8 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         if (tile == 9) return launch_patch(d, 8, s);
         if (tile == 10) return launch_patch(d, 4, s);
     }
-    if constexpr (NS == 1) {      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
-        if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);
+    if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
+    if constexpr (NS == 1) {
         if (tile == 8) return launch<256, 256, NS, CONV, 32>(d, s);
     }
     if constexpr (NS == 1) {      // BK = 64 variants (bf16 mode only: the bf16x3 planes would not fit the LDS budget)
@@ -1631,6 +1801,7 @@ int frido_igemm_init() {
     FRIDO_SET_ALL(128, 128); FRIDO_SET_ALL(128, 192); FRIDO_SET_ALL(64, 64);
     FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
 #undef FRIDO_SET_ALL
+    rc |= set_attr<256, 128, 2, true, 32>() | set_attr<256, 128, 2, false, 32>();
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
           set_attr<256, 256, 1, false, 32>() | set_attr<256, 128, 1, true, 64>() | set_attr<256, 128, 1, false, 64>();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,

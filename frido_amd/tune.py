@@ -1,7 +1,7 @@
 """Plan-time tile selection for the implicit-GEMM kernel: each distinct GEMM signature is timed once per
 process on scratch buffers with every tile shape (HIP events on the launch stream) and the fastest wins.
 Disable with FRIDO_TUNE=0 (the C library's static heuristic is used instead).  FRIDO_TUNE_CACHE=<file> persists the
-choices across processes (JSON; keyed by the GEMM signature and the size of libfrido_hip.so, so a rebuilt library starts
+choices across processes (JSON; keyed by the GEMM signature and a content hash of libfrido_hip.so, so a rebuilt library starts
 over) -- used to profile under rocprofv3 --pmc, where re-timing thousands of candidates would take hours."""
 import atexit
 import ctypes as C
@@ -32,7 +32,9 @@ def _lib_tag():
     if os.environ.get("FRIDO_TUNE_TAG"):      # A/B of two library builds with the SAME pinned tiles (tools/ab_lib.sh)
         return os.environ["FRIDO_TUNE_TAG"]
     try:
-        return str(os.path.getsize(_lib.LIB_PATH))
+        import hashlib
+        with open(_lib.LIB_PATH, "rb") as f:      # content hash: two builds of equal size must not share pinned tiles
+            return hashlib.sha256(f.read()).hexdigest()[:16]
     except OSError:
         return "?"
 
@@ -51,8 +53,8 @@ def _load_cache():
 
 
 def _save_cache():
-    if CACHE_FILE and _dirty:
-        tmp = CACHE_FILE + ".tmp"
+    if CACHE_FILE and _dirty and os.environ.get("RANK", "0") == "0":      # one writer under torch.distributed.run
+        tmp = f"{CACHE_FILE}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
             json.dump({"lib": _lib_tag(), "entries": [[list(k), list(v)] for k, v in _cache.items()]}, f)
         os.replace(tmp, CACHE_FILE)
@@ -155,11 +157,12 @@ def best_tile(st, device, stream):
         # BK = 64 halves the barrier count but costs a ring stage of occupancy: it only wins on small-M shapes
         k64 = (st.nsplit == 1 and st.K % 64 == 0 and st.K2 % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
                and (st.M * st.batch <= 4096 or K64_ALL))
-        big = st.nsplit == 1 and (sk == 1 or BIG_SPLITK) and st.M >= 512 and st.N >= 96
+        big = (sk == 1 or BIG_SPLITK) and st.M >= 512 and st.N >= 96
         # tile 9 = patch-staged 3x3 kernel (igemm.hip patch_ok; the library rejects it when it does not apply)
         patch = (st.conv and st.nsplit == 1 and st.batch == 1 and st.kh == 3 and st.stride == 1 and not (st.up_shift or st.dn_shift)
                  and not st.up2_phase and st.M % 128 == 0 and st.M >= 4096 and st.N >= 96 and sk <= (st.Cin + st.K2) // 32)
-        for tile in TILES + (TILES64 if k64 else ()) + (TILES8W if big else ()) + ((17,) if big and k64 else ()) + ((9, 10) if patch else ()):
+        big_tiles = (TILES8W if st.nsplit == 1 else (7,)) if big else ()      # bf16x3: the 256 x 128 tile only
+        for tile in TILES + (TILES64 if k64 else ()) + big_tiles + ((17,) if big and k64 else ()) + ((9, 10) if patch else ()):
             if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue
             t.tile = tile

@@ -522,8 +522,8 @@ def test_gemm_direct_epilogue_every_tile(nsplit, out, tile):
     """The store-from-registers epilogue (transposed accumulators, permuted weight rows): alpha, bias and a stream-dtype residual,
     stream or operand output, on every tile variant; M = 300 and N = 352 (a multiple of 32 and of no tile width) mask rows and
     whole 8-column groups; K = 320 gives the BK = 64 pipelined loop an odd number of k-steps per parity (5 stages)."""
-    if tile in (7, 8) and nsplit == 2 or tile >= 11 and nsplit == 2:
-        pytest.skip("8-wave and BK = 64 tiles are bf16-mode tiles")
+    if tile == 8 and nsplit == 2 or tile >= 11 and nsplit == 2:
+        pytest.skip("the 256 x 256 and BK = 64 tiles are bf16-mode tiles")
     M, N, K = 300, 352, 320
     a, w, bias, res = _t("da", M, K), _t("dw", N, K) / np.sqrt(K), _t("db", N), _t("dr", M, N)
     b = _builder(nsplit, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
@@ -558,14 +558,44 @@ def test_pipelined_loop_short_k(tile, K):
     assert _relerr(o.to_f32().cpu(), a @ w.t() + bias) < _tol(1)
 
 
+@pytest.mark.parametrize("conv", [False, True])
+@pytest.mark.parametrize("K", [32, 64, 96, 160, 352])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+def test_bf16x3_pipelined_loop_short_k(tile, K, conv):
+    """The bf16x3 virtual-k-step loop (hi*hi, hi*lo, lo*hi per stage, fragment sets rotating between stages) at 1, 2, 3, 5 and 11
+    ring stages: prologue only / no refill / first refill / odd and even stage parities / wrap-around of the 2-4 slot ring; dense
+    and as a 1x1 (K = Cin) / 3x3 (K = 9 * 32 ... ) convolution whose taps re-base the DMA pointers between stages."""
+    if conv:
+        B, H, W, Cin, N = 2, 12, 12, K, 224           # 3x3 conv: 9 K / 32 stages, zero-padded border taps
+        x, w, bias = _t("xa", B * H * W, Cin), _t("xw", N, Cin, 3, 3) / np.sqrt(9 * Cin), _t("xb", N)
+        b = _builder(2, {"c.weight": w.cuda(), "c.bias": bias.cuda()})
+        xd = x.cuda()
+        a_op = b.pack(xd.data_ptr(), 1, B * H * W, Cin, 0, Cin)
+        o = b.conv(a_op, B, H, W, "c", out="f32_strict")
+        b.prog.ops[-1][1].tile = tile
+        _run(b)
+        ref = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, N)
+        assert _relerr(o.view().float().cpu(), ref) < _tol(2)
+        return
+    M, N = 272, 224
+    a, w, bias = _t("sa", M, K), _t("sw", N, K) / np.sqrt(K), _t("sb", N)
+    b = _builder(2, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+    ad = a.cuda()
+    a_op = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+    o = b.linear(a_op, "w", out="op")
+    b.prog.ops[-1][1].tile = tile
+    _run(b)
+    assert _relerr(o.to_f32().cpu(), a @ w.t() + bias) < _tol(2)
+
+
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 11, 12, 14, 17])
 def test_fused_geglu_projection_every_tile(nsplit, tile):
     """The GEGLU epilogue has two forms: tiles with four-fold n-tile counts (128 / 256 columns) deal the packed rows so that a
     lane owns value and gate of 8 consecutive outputs (direct stores); the others keep the [a | gate] order and go through LDS.
     M is ragged and 2H = 1344 is a multiple of 64 but of no tile width, so every tile masks rows AND columns."""
-    if nsplit == 2 and tile >= 11:
-        pytest.skip("BK = 64 tiles are bf16-mode tiles")
+    if nsplit == 2 and (tile >= 11 or tile == 8):
+        pytest.skip("the 256 x 256 and BK = 64 tiles are bf16-mode tiles")
     M, C, H = 300, 128, 672
     x, w, bias = _t("gx", M, C), _t("gw", 2 * H, C) / np.sqrt(C), _t("gb", 2 * H)
     b = _builder(nsplit, {"p.weight": w.cuda(), "p.bias": bias.cuda()})

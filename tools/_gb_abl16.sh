@@ -1,0 +1,7 @@
+for shape in "dense 16384 384 1536" "dense 16384 384 384" "dense 4096 576 2304" "geglu 16384 1536 384"; do
+  for m in 0 16 ; do
+    L=frido_amd/libfrido_hip.so; [ $m != 0 ] && L=tools/ablate/libfrido_abl_$m.so
+    echo "== $shape ablate=$m"
+    FRIDO_LIB=$PWD/$L python tools/gemm_bench.py $shape 2 7,1,2 2>&1 | grep -E "tile|rror"
+  done
+done

@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
-"""Where does a kernel spill?  tools/spill_sites.py file.s [name-filter]: per kernel, every scratch_ access with its position
-relative to the first / last v_mfma of the function (spills outside the MFMA range sit in the prologue / epilogue)."""
-import re, sys
-lines = open(sys.argv[1]).read().split('\n')
-filt = sys.argv[2] if len(sys.argv) > 2 else ''
-starts = [(i, l.split(':')[0]) for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l)]
-starts.append((len(lines), None))
-for (a, name), (b, _) in zip(starts, starts[1:]):
-    if filt not in name:
-        continue
-    body = lines[a:b]
-    mf = [i for i, l in enumerate(body) if 'v_mfma' in l]
-    sc = [(i, l.strip()) for i, l in enumerate(body) if 'scratch_' in l]
-    if not sc:
-        continue
-    inside = [x for x in sc if mf and mf[0] < x[0] < mf[-1]]
-    print(f"{name}: {len(body)} lines, mfma lines {mf[0] if mf else None}..{mf[-1] if mf else None} ({len(mf)}), "
-          f"scratch ops {len(sc)}, between first and last mfma {len(inside)}")
-    for i, l in sc:
-        print('   ', i, l[:70])
+"""Where does a kernel spill?  python tools/spill_sites.py <file.s> <mangled-name-substring>
+Lists every scratch_load / scratch_store of the kernel with the number of MFMAs that precede it in program order (spills before the
+first or after the last MFMA are prologue / epilogue; anything in between sits in the main loop)."""
+import sys
+
+lines = open(sys.argv[1]).read().split("\n")
+pat = sys.argv[2]
+start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and pat in l and ":" in l)
+end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+body = lines[start:end]
+nm = 0
+sites = []
+for i, l in enumerate(body):
+    if "v_mfma" in l:
+        nm += 1
+    if "scratch_" in l:
+        sites.append((i, nm, l.strip().split(";")[0]))
+print(f"{len(body)} lines, {nm} MFMAs, {len(sites)} scratch ops")
+for i, k, l in sites:
+    print(f"  line {i:6d}  after {k:4d} MFMAs  {l}")
