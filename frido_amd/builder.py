@@ -2,6 +2,7 @@
 descriptors, owning the packed-weight cache and the activation pool.  The U-Net / VQGAN plans
 (unet_plan.py, vqgan_plan.py) are written against this API; the kernel unit tests drive it directly.
 """
+import contextlib
 import ctypes as C_
 import os
 
@@ -36,6 +37,18 @@ class Builder:
         # bf16 mode keeps the residual stream itself in bf16 (it then doubles as the MFMA operand: no pack passes);
         # bf16x3 (fp32-class parity mode) keeps an f32 stream
         self.stream_bf16 = nsplit == 1
+
+    @contextlib.contextmanager
+    def persist_scope(self):
+        """Persistent tensors created inside the scope (hoisted SPADE maps, V^T operands, bias / table tensors) are collected in
+        the yielded list INSTEAD of the builder's own: the caller (a SamplerEngine) owns them, so dropping the engine -- e.g. its
+        eviction from the per-denoiser LRU cache -- frees their HBM.  The packed-weight cache stays shared."""
+        outer, mine = self._persist, []
+        self._persist = mine
+        try:
+            yield mine
+        finally:
+            self._persist = outer
 
     # ---- programs ------------------------------------------------------------------------------
     def new_prog(self):

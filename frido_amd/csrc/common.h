@@ -55,6 +55,8 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float r = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(r, x);
 }
+// OpenAI CLIP's QuickGELU (clip/model.py): x * sigmoid(1.702 x)
+__device__ __forceinline__ float quickgelu_f(float v) { return v / (1.0f + __expf(-1.702f * v)); }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

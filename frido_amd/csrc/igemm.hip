@@ -489,6 +489,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 if (d.act == FRIDO_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (d.act == FRIDO_ACT_SILU) x = silu_f(x);
                 else if (d.act == FRIDO_ACT_GELU) x = gelu_f(x);
+                else if (d.act == FRIDO_ACT_QUICKGELU) x = quickgelu_f(x);
                 if (d.residual) x += load_act1(d.residual, rs_base + (int64_t)m * d.ldr + n, d.res_bf16);
                 const int64_t mo = out_row(m);
                 if (d.out_f32) store_act1(d.out_f32, of_base + mo * d.ldo + n, d.out_bf16, x);
@@ -532,6 +533,9 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             } else if (d.act == FRIDO_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if (d.act == FRIDO_ACT_QUICKGELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = quickgelu_f(v[e]);
             }
             if (d.residual) {
                 const int64_t ro = rs_base + (int64_t)m * d.ldr + n;
@@ -760,7 +764,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             bptr[j] += BK;
         }
     };
-    auto issue_end = [&]() { ++ktn; --seg_left; };
+    auto advance = [&]() { ++ktn; --seg_left; };      // the stage of k-tile ktn has been issued
+    auto issue_end = [&]() { advance(); };
     auto issue = [&](int buf) {
         if (seg_left == 0) retap();
         unsigned char* sb = smem + buf * STAGE + wave * 1024;
@@ -780,8 +785,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 __builtin_amdgcn_global_load_lds((gptr_t)(bptr[j] + b_lo), (lptr_t)(sb + PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
             bptr[j] += KADV;
         }
-        ++ktn;
-        --seg_left;
+        advance();
     };
 
     f32x4 acc[TM][TN];
@@ -947,15 +951,22 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 const frido_bf16* src = (pl && astep[idx]) ? aptr[idx] + alo_cur : aptr[idx];
                 if constexpr (FRIDO_ABLATE & 32) src = reinterpret_cast<const frido_bf16*>(zero_addr) + (lane & 3) * 8;   // same 64 bytes for every piece
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + idx * (NW * 1024)), 16, 0, 0);
-                if constexpr (pl == 1) aptr[idx] += astep[idx];
             } else {
                 constexpr int j = idx - JA;
                 const frido_bf16* srcb = bptr[j] + (pl ? b_lo : 0);
                 if constexpr (FRIDO_ABLATE & 32) srcb = reinterpret_cast<const frido_bf16*>(zero_addr) + (lane & 3) * 8;
                 __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
-                if constexpr (pl == 1) bptr[j] += KADV;
             }
         };
+        auto refill_end = [&]() {                                    // every piece of the stage is out: step the source pointers
+#pragma unroll
+            for (int j = 0; j < JA; ++j) aptr[j] += astep[j];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) bptr[j] += KADV;
+            issue_end();
+        };
+        // (ablation 256: waves 4..7 of an 8-wave workgroup take the refill's pieces half a window later than waves 0..3)
+        const bool late = (FRIDO_ABLATE & 256) && NW == 8 && wave >= 4;
         auto vstep = [&](auto vc, auto qc, auto prec, int kt) {
             constexpr int V = decltype(vc)::value, Q = decltype(qc)::value;
             constexpr bool PRE = decltype(prec)::value;             // v2 only: a next stage exists
@@ -995,9 +1006,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(FRIDO_ABLATE & 8)) {
+                    if constexpr (FRIDO_ABLATE & 128) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[BS][j], fa[AS][i], acc[i][j], 0, 0, 0);   // weights first: C^T tiles
+                    if constexpr (FRIDO_ABLATE & 128) __builtin_amdgcn_s_setprio(0);
                 } else {
                     asm volatile("" :: "v"(fb[BS][j]), "v"(fa[AS][0]), "v"(fa[AS][TM - 1]));      // keep the fragment reads alive
                 }
@@ -1005,8 +1018,10 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 constexpr int g = V == 2 ? j : (V == 0 ? TN + j : 2 * TN + j);          // group index within the refill begun at v2
                 if constexpr (g < NG) {
                     if (dma) {
-                        static_for<g * NPC / NG, (g + 1) * NPC / NG>([&](auto pc) { piece(pc); });
-                        if constexpr (g == NG - 1) issue_end();
+                        constexpr int g2 = (g + NG / 2) % NG;
+                        if (!late) static_for<g * NPC / NG, (g + 1) * NPC / NG>([&](auto pc) { piece(pc); });
+                        else static_for<g2 * NPC / NG, (g2 + 1) * NPC / NG>([&](auto pc) { piece(pc); });
+                        if constexpr (g == NG - 1) refill_end();
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1620,6 +1635,9 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) 
         } else if (d.act == FRIDO_ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (d.act == FRIDO_ACT_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = quickgelu_f(v[e]);
         }
         if (d.residual) {
             const int64_t ro = (int64_t)m * d.ldr + n;
@@ -1675,6 +1693,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
         if (d.act == FRIDO_ACT_RELU) v = fmaxf(v, 0.f);
         else if (d.act == FRIDO_ACT_SILU) v = silu_f(v);
         else if (d.act == FRIDO_ACT_GELU) v = gelu_f(v);
+        else if (d.act == FRIDO_ACT_QUICKGELU) v = quickgelu_f(v);
         if (d.residual) v += load_act1(d.residual, (int64_t)m * d.ldr + n, d.res_bf16);
         if (d.out_f32) store_act1(d.out_f32, (int64_t)m * d.ldo + n, d.out_bf16, v);
         if (d.out_op) store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);

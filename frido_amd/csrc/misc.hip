@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const FridoEmbed d) {
         int64_t tk = d.tokens[r];
         tk = tk < 0 ? 0 : (tk >= d.vocab ? d.vocab - 1 : tk);
         const float4 a = *reinterpret_cast<const float4*>(d.tok + tk * d.D + c);
-        const float4 p = *reinterpret_cast<const float4*>(d.pos + (r % d.n) * d.D + c);
+        const float4 p = d.pos ? *reinterpret_cast<const float4*>(d.pos + (r % d.n) * d.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(d.out + r * d.D + c) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
     }
 }
@@ -423,7 +423,7 @@ extern "C" int frido_place(const FridoPlace* d, frido_stream_t s) {
 }
 
 extern "C" int frido_embed(const FridoEmbed* d, frido_stream_t s) {
-    FRIDO_REQUIRE(d && d->tokens && d->tok && d->pos && d->out && d->rows > 0 && d->n > 0 && (d->D & 3) == 0 && d->vocab > 0,
+    FRIDO_REQUIRE(d && d->tokens && d->tok && d->out && d->rows > 0 && d->n > 0 && (d->D & 3) == 0 && d->vocab > 0,
                   "bad arguments");
     hipLaunchKernelGGL(embed_kernel, dim3(grid_for((int64_t)d->rows * (d->D >> 2))), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("embed");

@@ -458,12 +458,13 @@ __global__ __launch_bounds__(256) void softmax_kernel(const FridoSoftmax d) {
     constexpr int MAXV = 64;
     float v[MAXV];
     const int nv = (d.N + 63) >> 6;
+    const int nvis = d.causal_nq > 0 ? min(d.N, row % d.causal_nq + 1) : d.N;      // keys this row may see
     float mx = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         if (i < nv) {
             const int c = lane + i * 64;
-            v[i] = c < d.N ? x[c] : -3.0e38f;
+            v[i] = c < nvis ? x[c] : -3.0e38f;
             mx = fmaxf(mx, v[i]);
         }
     }
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(const FridoSoftmax d) {
     for (int i = 0; i < MAXV; ++i) {
         if (i < nv) {
             const int c = lane + i * 64;
-            v[i] = c < d.N ? __expf(v[i] - mx) : 0.f;
+            v[i] = c < nvis ? __expf(v[i] - mx) : 0.f;
             s += v[i];
         }
     }
@@ -487,6 +488,19 @@ __global__ __launch_bounds__(256) void softmax_kernel(const FridoSoftmax d) {
             if (c < d.Npad) store_op1(o, d.out_lo, d.nsplit, c, i < nv ? v[i] * inv : 0.f);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row L2 normalisation (one wave per row): the CLIP text embedding's z / ||z|| (encoders/modules.py:213-214).
+__global__ __launch_bounds__(256) void l2norm_kernel(const FridoL2Norm d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.rows) return;
+    const float* x = d.x + (int64_t)row * d.C;
+    float s = 0.f;
+    for (int c = lane; c < d.C; c += 64) s = fmaf(x[c], x[c], s);
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+    for (int c = lane; c < d.C; c += 64) d.out[(int64_t)row * d.C + c] = x[c] * inv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -584,6 +598,12 @@ extern "C" int frido_softmax(const FridoSoftmax* d, frido_stream_t s) {
     FRIDO_REQUIRE(d->N > 0 && d->N <= 4096 && d->Npad >= d->N && d->Npad <= 4096 && d->rows > 0, "N must be in [1, 4096]");
     hipLaunchKernelGGL(softmax_kernel, dim3((d->rows + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("softmax");
+}
+
+extern "C" int frido_l2norm(const FridoL2Norm* d, frido_stream_t s) {
+    FRIDO_REQUIRE(d && d->x && d->out && d->rows > 0 && d->C > 0, "bad arguments");
+    hipLaunchKernelGGL(l2norm_kernel, dim3((d->rows + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
+    return frido_check_launch("l2norm");
 }
 
 extern "C" int frido_geglu(const FridoGeglu* d, frido_stream_t s) {

@@ -59,6 +59,7 @@ int run_one(const FridoOp& op, frido_stream_t s) {
         case FRIDO_OP_GN_FUSED: return frido_gn_fused(&op.u.gn_apply, s);
         case FRIDO_OP_COPY: return frido_copy(&op.u.copy, s);
         case FRIDO_OP_ATTN_FLASH: return frido_attn_flash(&op.u.attn_small, s);
+        case FRIDO_OP_L2NORM: return frido_l2norm(&op.u.l2norm, s);
         default:
             frido_set_error("frido_run: unknown op kind %d", op.kind);
             return FRIDO_EINVAL;
@@ -299,6 +300,7 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
         case FRIDO_OP_COPY: return sizeof(FridoCopy);
         case FRIDO_OP_ATTN_FLASH: return sizeof(FridoAttnSmall);
         case FRIDO_OP_SYNC: return sizeof(FridoSync);
+        case FRIDO_OP_L2NORM: return sizeof(FridoL2Norm);
         default: return -1;
     }
 }

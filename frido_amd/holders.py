@@ -313,3 +313,40 @@ def build_bert_params(root, n_embed, n_layer, vocab_size, max_seq_len, heads=8, 
     tr.norm = Affine(n_embed)
     tr.to_logits = Lin(n_embed, vocab_size)
     root.transformer = tr
+
+
+# ---- cond stage: FrozenCLIPTextEmbedder.model = OpenAI CLIP (text tower only; clip/model.py CLIP.__init__) ------------------
+CLIP_TEXT_ARCH = {      # version -> (embed_dim, context_length, vocab_size, transformer_width, transformer_heads, transformer_layers)
+    "ViT-L/14": (768, 77, 49408, 768, 12, 12),
+    "ViT-B/32": (512, 77, 49408, 512, 8, 12),
+    "ViT-B/16": (512, 77, 49408, 512, 8, 12),
+}
+
+
+def build_clip_text_params(root, embed_dim, context_length, vocab_size, width, heads, layers):
+    """Parameter tree of the text side of clip.model.CLIP under `root.model` (state_dict keys `model.token_embedding.weight`,
+    `model.positional_embedding`, `model.transformer.resblocks.N.{ln_1,attn.in_proj_*,attn.out_proj,ln_2,mlp.c_fc,mlp.c_proj}`,
+    `model.ln_final`, `model.text_projection`, `model.logit_scale`): a reference checkpoint's `cond_stage_model.model.*` keys
+    load into it; its `model.visual.*` keys are simply unexpected keys of a strict=False load."""
+    m = Nop()
+    m.token_embedding = Emb(vocab_size, width)
+    m.positional_embedding = _p(context_length, width)
+    blocks = []
+    for _ in range(layers):
+        blk = Nop()
+        blk.ln_1, blk.ln_2 = Affine(width), Affine(width)
+        attn = Nop()
+        attn.in_proj_weight, attn.in_proj_bias = _p(3 * width, width), _p(3 * width)
+        attn.out_proj = Lin(width, width)
+        blk.attn = attn
+        mlp = Nop()
+        mlp.c_fc, mlp.c_proj = Lin(width, 4 * width), Lin(4 * width, width)
+        blk.mlp = mlp
+        blocks.append(blk)
+    tr = Nop()
+    tr.resblocks = seq(*blocks)
+    m.transformer = tr
+    m.ln_final = Affine(width)
+    m.text_projection = _p(width, embed_dim)
+    m.logit_scale = nn.Parameter(torch.empty(()), requires_grad=False)
+    root.model = m

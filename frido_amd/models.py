@@ -245,9 +245,8 @@ class BERTEmbedder(_Versioned, nn.Module):
     def __init__(self, n_embed, n_layer, vocab_size=30522, max_seq_len=77, device="cuda", use_tokenizer=True,
                  embedding_dropout=0.0, cond_key="", precision=None):
         super().__init__()
-        if use_tokenizer:
-            raise NotImplementedError("BERTEmbedder(use_tokenizer=True) needs the HF 'bert-base-uncased' tokenizer files, "
-                                      "which are not reachable offline; every shipped layout2img config sets use_tokenizer: False")
+        self.use_tknz_fn = use_tokenizer      # strings -> ids needs the HF tokenizer files: resolved lazily, at encode time
+        self.tokenizer = None
         self.n_embed, self.n_layer, self.vocab_size, self.max_seq_len = n_embed, n_layer, vocab_size, max_seq_len
         self.cond_key, self.precision = cond_key, precision
         holders.build_bert_params(self, n_embed, n_layer, vocab_size, max_seq_len)
@@ -261,6 +260,8 @@ class BERTEmbedder(_Versioned, nn.Module):
     @torch.no_grad()
     def forward(self, text, return_token=False):
         tokens = text[self.cond_key] if self.cond_key != "" else text
+        if not torch.is_tensor(tokens):       # captions as strings (use_tokenizer=True configs): encoders/modules.py:63-64,99-104
+            tokens = self._tokenize(tokens)
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             _no_cpu("BERTEmbedder", dev)
@@ -286,31 +287,106 @@ class BERTEmbedder(_Versioned, nn.Module):
     def encode(self, text):
         return self(text)
 
+    def _tokenize(self, text):
+        """BERTTokenizer of the reference (encoders/modules.py:57-82): HF `bert-base-uncased`, padded / truncated to max_seq_len.
+        The vocabulary files are not reachable offline, so this only works where `transformers` finds them locally; token-id
+        tensors and finished conditioning tensors never come here."""
+        if self.tokenizer is None:
+            try:
+                from transformers import BertTokenizerFast
+                tk = BertTokenizerFast.from_pretrained("bert-base-uncased", local_files_only=True)
+                if tk.vocab_size < 30000:       # transformers >= 5 hands back an EMPTY tokenizer when the files are missing
+                    raise FileNotFoundError("vocabulary not found")
+                self.tokenizer = tk
+            except Exception as e:
+                raise NotImplementedError(
+                    "BERTEmbedder: captions given as strings need the HF 'bert-base-uncased' tokenizer files, which are not "
+                    f"reachable offline ({type(e).__name__}); pass token ids ([B, n] int64) or the conditioning tensor instead") from None
+        enc = self.tokenizer(text, truncation=True, max_length=self.max_seq_len, return_length=True, return_overflowing_tokens=False,
+                             padding="max_length", return_tensors="pt")
+        return enc["input_ids"]
 
-class FrozenCLIPTextEmbedder(nn.Module):
+
+class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
     """cond_stage_config.target of configs/frido/t2i/frido_f16f8_coco_clip.yaml:80 (reference:
-    frido/modules/encoders/modules.py:188-219: OpenAI CLIP ViT-L/14 text tower -> ONE L2-normalised 768-d token per caption,
-    repeated n_repeat times).  The CLIP package and its weights are not reachable offline (parity
-    unpinned), so the class keeps the constructor / attribute surface and raises a clear error when asked to encode; the
-    t2i path is driven with conditioning tensors (`model.get_learned_conditioning` bypassed) in tests and bench."""
+    frido/modules/encoders/modules.py:188-219): the text tower of OpenAI CLIP -> ONE L2-normalised embedding per caption,
+    `encode` adds the token axis and repeats it n_repeat times.  The tower runs on the HIP engine (clip_plan.ClipTextPlan);
+    its weights live under `self.model` with OpenAI CLIP's state_dict names, so a reference checkpoint's
+    `cond_stage_model.model.*` keys load.  `forward` takes token ids ([B, 77] int64, what `clip.tokenize` returns); captions as
+    strings need the CLIP byte-pair vocabulary file, which is part of the un-vendored `clip` package: pass `tokenizer=` (any
+    callable list[str] -> LongTensor [B, 77]) or install `clip`; without either a clear error is raised at encode time.
+    `arch` overrides the (embed_dim, context_length, vocab, width, heads, layers) of `version` (tests use a reduced tower)."""
 
-    def __init__(self, version="ViT-L/14", device="cuda", max_length=77, n_repeat=1, normalize=True):
+    def __init__(self, version="ViT-L/14", device="cuda", max_length=77, n_repeat=1, normalize=True, arch=None, tokenizer=None,
+                 precision=None):
         super().__init__()
         self.version, self.device, self.max_length = version, device, max_length
         self.n_repeat, self.normalize, self.use_tknz_fn = n_repeat, normalize, True
-        self.model = None
+        self.precision, self.tokenizer = precision, tokenizer
+        if arch is None:
+            if version not in holders.CLIP_TEXT_ARCH:
+                raise NotImplementedError(f"FrozenCLIPTextEmbedder: unknown CLIP version '{version}' "
+                                          f"(known: {sorted(holders.CLIP_TEXT_ARCH)}); pass arch=(embed_dim, ctx, vocab, width, heads, layers)")
+            arch = holders.CLIP_TEXT_ARCH[version]
+        self.arch = tuple(arch)
+        holders.build_clip_text_params(self, *self.arch)
+        self._init_versioning()
+        self._plans = {}
+
+    def invalidate(self):
+        self._rt = None
+        self._plans = {}
 
     def freeze(self):
         for p in self.parameters():
             p.requires_grad = False
 
+    def _tokens(self, text):
+        if torch.is_tensor(text):
+            return text
+        if self.tokenizer is not None:
+            return self.tokenizer(text)
+        try:
+            import clip                                        # the reference's own dependency, when it is installed
+            return clip.tokenize(text)
+        except ImportError:
+            raise NotImplementedError(
+                "FrozenCLIPTextEmbedder: captions given as strings need CLIP's byte-pair vocabulary (`clip.tokenize`); the `clip` "
+                "package is not reachable offline -- pass token ids ([B, 77] int64), a tokenizer= callable, or the finished "
+                "[B, n_repeat, embed_dim] embedding to the sampler as `conditioning`") from None
+
+    @torch.no_grad()
     def forward(self, text):
-        raise NotImplementedError(
-            f"FrozenCLIPTextEmbedder: the OpenAI `clip` package and the '{self.version}' weights are not reachable "
-            "offline; pass the [B, n_repeat, 768] L2-normalised text embedding to the sampler as `conditioning` instead")
+        tokens = self._tokens(text)
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            _no_cpu("FrozenCLIPTextEmbedder", dev)
+        tokens = tokens.to(dev).long()
+        B, n = tokens.shape
+        embed_dim, ctx, vocab, width, heads, layers = self.arch
+        assert n <= ctx, f"{n} tokens > context length {ctx}"
+        from .builder import Builder
+        from .clip_plan import ClipTextPlan
+        from .engine import current_stream_ptr, require_gpu
+        from .runtime import _weights_of
+        if self._rt is None:
+            require_gpu(dev)
+            self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev))
+        key = (B, n)
+        if key not in self._plans:
+            self._plans[key] = ClipTextPlan(self._rt, B=B, n=n, width=width, layers=layers, heads=heads, vocab=vocab,
+                                            embed_dim=embed_dim, normalize=self.normalize)
+        plan = self._plans[key]
+        plan.tokens.copy_(tokens.reshape(-1))
+        plan.eot_rows.copy_(tokens.argmax(dim=-1) + torch.arange(B, device=dev) * n)      # clip/model.py: the EOT token has the highest id
+        plan.prog.run(current_stream_ptr(dev))
+        return plan.out.clone()
 
     def encode(self, text):
-        return self(text)
+        z = self(text)
+        if z.ndim == 2:
+            z = z[:, None, :]
+        return z.expand(-1, self.n_repeat, -1).contiguous()      # repeat(z, 'b 1 d -> b k d', k=n_repeat)
 
 
 # ---- EMA shadow (frido/modules/ema.py) ---------------------------------------------------------------

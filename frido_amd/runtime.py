@@ -61,7 +61,8 @@ class DenoiserRuntime:
     def builder_for(self, replica):
         """Builder of sampler replica `replica`.  Replica 0 is the runtime's own; further replicas get their OWN activation
         pool, persistent buffers and split-K workspace (they share the f32 weight tensors, not the scratch), so that their
-        captured step bodies can be replayed CONCURRENTLY on different streams (pipeline.sample_images substreams)."""
+        captured step bodies can be replayed CONCURRENTLY on different streams (only tools/dual_stream_exp.py does that: the
+        measured gain of two concurrent sub-batches was +1 %, so pipeline.sample_images runs ONE replica)."""
         if replica not in self._replicas:
             self._replicas[replica] = Builder(self.device, self.nsplit, self.b.w, ws_tag=f":r{replica}")
         return self._replicas[replica]
@@ -118,10 +119,12 @@ class SamplerEngine:
         self.x = torch.zeros(B, H * W, C, dtype=torch.float32, device=self.dev)
         self.pred_x0 = torch.zeros_like(self.x)
         self.stages = []
-        for s in range(self.num_stage):
-            plan = UNetStagePlan(self.b, cfg, B=B, H=H, W=W, nctx=nctx, stage=s, x_state=self.x, temb_rows=self.n_steps,
-                                 per_sample_t=False, step_ptr=self.step.data_ptr(), xrep=self.xrep)
-            self.stages.append(plan)
+        with self.b.persist_scope() as owned:       # this engine owns its plans' persistent buffers: evicting it frees them
+            for s in range(self.num_stage):
+                plan = UNetStagePlan(self.b, cfg, B=B, H=H, W=W, nctx=nctx, stage=s, x_state=self.x, temb_rows=self.n_steps,
+                                     per_sample_t=False, step_ptr=self.step.data_ptr(), xrep=self.xrep)
+                self.stages.append(plan)
+        self._persist = owned
         self.graphs = {}
         self.noise_buf = None
         self._stream = None

@@ -50,7 +50,8 @@ class _SamplerBase:
         if key in cache:
             cache.move_to_end(key)
         else:
-            while len(cache) >= ENGINE_CACHE_SIZE:      # least-recently-used engine goes (frees its HBM)
+            while len(cache) >= ENGINE_CACHE_SIZE:      # least-recently-used engine goes; it owns its plans' persistent buffers
+                # (Builder.persist_scope) and graphs, so its HBM is released with it -- the activation pool is shared and reused
                 cache.popitem(last=False)
             cache[key] = SamplerEngine(rt.builder_for(replica), unet.cfg, B=B, C=C, H=H, W=W, nctx=nctx, S=S, eta=eta, kind=self.KIND,
                                        alphas_cumprod=self.model.alphas_cumprod.detach().float().cpu().numpy(),

@@ -27,6 +27,8 @@ def fill_tensor(name, shape):
     if "embedding.weight" in name or name.endswith("emb.weight") or "stage_emb" in name:
         # VQ codebooks / token / stage embeddings: O(1) entries so that codes are well separated
         return (rng.standard_normal(shape) * (0.5 if "stage_emb" in name else 1.0)).astype(np.float32)
+    if leaf in ("in_proj_weight", "text_projection") and len(shape) == 2:      # OpenAI CLIP's bare matrices: fan-in scaling too
+        return (rng.standard_normal(shape) / np.sqrt(shape[1] if leaf == "in_proj_weight" else shape[0])).astype(np.float32)
     if leaf == "weight" and len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))
         return (rng.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)

@@ -53,7 +53,8 @@ def _load_cache():
 
 
 def _save_cache():
-    if CACHE_FILE and _dirty and os.environ.get("RANK", "0") == "0":      # one writer under torch.distributed.run
+    if CACHE_FILE and _dirty and os.environ.get("RANK", "0") == "0" and os.environ.get("FRIDO_TUNE_CACHE_READONLY", "0") == "0":
+        # (one writer under torch.distributed.run; bench.py reads the tracked cache and only rewrites it under --retune)
         tmp = f"{CACHE_FILE}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
             json.dump({"lib": _lib_tag(), "entries": [[list(k), list(v)] for k, v in _cache.items()]}, f)

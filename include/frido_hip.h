@@ -31,7 +31,8 @@ typedef uint16_t frido_bf16;
 #define FRIDO_EHIP (-2)
 #define FRIDO_EUNSUPPORTED (-3)
 
-enum { FRIDO_ACT_NONE = 0, FRIDO_ACT_RELU = 1, FRIDO_ACT_SILU = 2, FRIDO_ACT_GELU = 3 /* exact erf GELU */ };
+enum { FRIDO_ACT_NONE = 0, FRIDO_ACT_RELU = 1, FRIDO_ACT_SILU = 2, FRIDO_ACT_GELU = 3 /* exact erf GELU */,
+       FRIDO_ACT_QUICKGELU = 4 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's text tower */ };
 
 /* ------------------------------------------------------------------------------------------
  * frido_gemm — implicit-GEMM on the MFMA pipe:  for z < batch:
@@ -143,6 +144,8 @@ typedef struct FridoLayerNorm {
 typedef struct FridoSoftmax {
     const float* x; int32_t rows, N, ld, Npad;
     int32_t nsplit; frido_bf16* out_op; int64_t out_lo;
+    int32_t causal_nq;          /* > 0: causal mask -- row r only sees keys 0 .. (r mod causal_nq) (CLIP text tower), the rest
+                                   of the row is written as zero */
 } FridoSoftmax;
 
 /* Fused attention core for SHORT key sequences (Nk <= 128): O = softmax(alpha * Q K^T) V in one launch, the score
@@ -261,7 +264,10 @@ typedef struct FridoPlace { const float* src; float* dst; int32_t B, h, w, Csrc,
 /* Token + absolute position embedding (frido/modules/x_transformer.py:25-36,620-622):
  * out[r][:] = tok[tokens[r]][:] + pos[r % n][:]   (f32, D % 4 == 0). */
 typedef struct FridoEmbed { const int64_t* tokens; const float* tok; const float* pos; float* out;
-                            int32_t rows, n, D, vocab; } FridoEmbed;
+                            int32_t rows, n, D, vocab; } FridoEmbed;      /* pos == NULL: plain row gather out[r] = tok[tokens[r]] */
+
+/* Row L2 normalisation out[r] = x[r] / ||x[r]||_2 (FrozenCLIPTextEmbedder.forward, frido/modules/encoders/modules.py:213-214). */
+typedef struct FridoL2Norm { const float* x; float* out; int32_t rows, C; } FridoL2Norm;
 
 /* Output conversion of scripts/sample_diffusion.py:115-121 (custom_to_np): NHWC f32 in [-1, 1] -> uint8 NHWC,
  * ((x + 1) * 127.5) clamped to [0, 255] and truncated. */
@@ -287,7 +293,7 @@ typedef struct FridoSync { int32_t from, to; } FridoSync;
 enum FridoOpKind {
     FRIDO_OP_GEMM = 1, FRIDO_OP_GN_STATS, FRIDO_OP_GN_APPLY, FRIDO_OP_LAYERNORM, FRIDO_OP_SOFTMAX,
     FRIDO_OP_GEGLU, FRIDO_OP_PACK, FRIDO_OP_RELAYOUT, FRIDO_OP_VQ, FRIDO_OP_SAMPLER_STEP,
-    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP_ATTN_FLASH, FRIDO_OP_SYNC, FRIDO_OP__COUNT
+    FRIDO_OP_HANDOFF, FRIDO_OP_RANDN, FRIDO_OP_STEP_ADD, FRIDO_OP_FILL, FRIDO_OP_TIME_EMB, FRIDO_OP_CONVT, FRIDO_OP_PLACE, FRIDO_OP_EMBED, FRIDO_OP_TO_U8, FRIDO_OP_ATTN_SMALL, FRIDO_OP_GN_FUSED, FRIDO_OP_COPY, FRIDO_OP_ATTN_FLASH, FRIDO_OP_SYNC, FRIDO_OP_L2NORM, FRIDO_OP__COUNT
 };
 
 /* A program is an array of tagged ops executed in order on one stream by the native executor. */
@@ -297,7 +303,7 @@ typedef struct FridoOp {
         FridoGemm gemm; FridoGnStats gn_stats; FridoGnApply gn_apply; FridoLayerNorm layernorm;
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
-        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small; FridoCopy copy; FridoSync sync;
+        FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small; FridoCopy copy; FridoSync sync; FridoL2Norm l2norm;
         char _size[384];
     } u;
 } FridoOp;
@@ -328,6 +334,7 @@ int frido_embed(const FridoEmbed* d, frido_stream_t s);
 int frido_to_u8(const FridoToU8* d, frido_stream_t s);
 int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s);
 int frido_copy(const FridoCopy* d, frido_stream_t s);
+int frido_l2norm(const FridoL2Norm* d, frido_stream_t s);
 /* Flash-style attention core for LONG key sequences on the same FridoAttnSmall descriptor (any Nk; d = dv in
  * {128, 256, 384, 512, 576}; Nq arbitrary): online softmax over 32-key tiles, the [Nq][Nk] score matrix is never formed.
  * Replaces the QK^T GEMM -> f32 scores -> softmax -> PV GEMM chain of frido/modules/attention.py:170-193 on the 32x32 /

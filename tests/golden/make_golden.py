@@ -419,6 +419,44 @@ def gen_sampler_xt():
     save("sampler_xt", **out)
 
 
+def gen_sampler_ddim200():
+    """BASELINE config 2's step count on config 1's plumbing: layout2i f8f4 at full width, B = 1, DDIM-200 eta = 1 (400 denoiser
+    forwards of the reference, ddim.py:116-186) + decode.  Same tokens / context as sampler_full."""
+    DDIM, PLMS = H.patch_samplers()
+    bcfg = dict(BERT_FULL, vocab_size=1024 + 256)
+    model = build_frido(UNET_FULL, VQ_FULL, bcfg)
+    tokens = torch.from_numpy(np.random.default_rng(11).integers(0, 1024, (1, 26)))
+    with torch.no_grad():
+        c = model.get_learned_conditioning(tokens)
+    out = {"tokens": tokens.numpy(), "c": c.numpy(), "scale_factor": model.scale_factor.numpy()}
+    _run_sampler(out, model, "ddim200", DDIM, 200, 1.0, 1.0, c, None, (6, 64, 64), 2, 50, 4)
+    save("sampler_ddim200", **out)
+
+
+def gen_sampler_512():
+    """BASELINE config 5, MULTI-STEP at its true size: the 3-stage DDIM loop (two hand-offs incl. the 4x4 block mean of stage 0,
+    ddim.py:146-149,177-185) on the 9 x 128 x 128 latent with 92 context tokens, S = 2, eta = 1, + the 512 x 512 decode."""
+    DDIM, PLMS = H.patch_samplers()
+    model = _frido_no_cond(UNET_512, VQ_512, 3)
+    c = T(seeded_normal("s512:ctx", (1, 92, 640)))
+    out = {"c": c.numpy(), "scale_factor": model.scale_factor.numpy()}
+    _run_sampler(out, model, "ddim2", DDIM, 2, 1.0, 1.0, c, None, (9, 128, 128), 3, 1, 8)
+    save("sampler_512", **out)
+
+
+def gen_shipped_cfgs():
+    """The `model:` tree of every configs/frido/**/*.yaml the reference ships, as JSON (data: the host test feeds each one to
+    instantiate_from_config)."""
+    import glob
+    import json
+    import yaml
+    root = os.path.join(H.REF if hasattr(H, "REF") else "/root/reference", "configs")
+    out = {os.path.relpath(f, root): yaml.safe_load(open(f))["model"] for f in sorted(glob.glob(os.path.join(root, "frido", "*", "*.yaml")))}
+    with open(os.path.join(HERE, "shipped_model_cfgs.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("shipped_model_cfgs.json:", len(out), "configs")
+
+
 GENS = {
     "schedules": gen_schedules,
     "unet_small": lambda: gen_unet("unet_small", UNET_SMALL, B=2, nctx=5, hw=16),
@@ -434,6 +472,9 @@ GENS = {
     "sampler_t2i": gen_sampler_t2i,
     "unet_512": gen_unet_512,
     "vq_512": gen_vq_512,
+    "sampler_ddim200": gen_sampler_ddim200,
+    "sampler_512": gen_sampler_512,
+    "shipped_cfgs": gen_shipped_cfgs,
 }
 
 if __name__ == "__main__":

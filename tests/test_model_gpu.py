@@ -5,6 +5,8 @@ Precision: bf16x3 (fp32-emulating MFMA path).  Stated tolerances, relative to th
   single denoiser forward     2e-4      multi-step sampler latents   1e-3
   VQGAN decode (same codes)   2e-4      decoded pixels end-to-end    1e-3 abs (north star), code flips reported
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -207,6 +209,43 @@ def test_bert_embedder_full_size_matches_oracle():
     sd = {"cond_stage_model." + k: torch.from_numpy(fill_tensor("cond_stage_model." + k, v.shape)) for k, v in m.state_dict().items()}
     ref = bert_embed(sd, tokens, cfg["n_layer"])
     assert _rel(m(tokens.cuda()), ref) < 3e-4
+
+
+def _clip_tokens(B, n, vocab, seed):
+    """Token rows shaped like clip.tokenize's: SOT, a few word ids, EOT (the highest id), zero padding."""
+    rng = np.random.default_rng(seed)
+    t = np.zeros((B, n), dtype=np.int64)
+    for b in range(B):
+        L = int(rng.integers(1, n - 2))
+        t[b, 0] = vocab - 2
+        t[b, 1:1 + L] = rng.integers(1, vocab - 2, L)
+        t[b, 1 + L] = vocab - 1
+    return torch.from_numpy(t)
+
+
+@pytest.mark.parametrize("arch", [(64, 16, 1000, 128, 4, 3), "ViT-L/14"], ids=["small", "ViT-L-14"])
+def test_clip_text_embedder_matches_oracle(arch):
+    """FrozenCLIPTextEmbedder (encoders/modules.py:188-219) on the HIP engine vs the oracle's restatement of OpenAI CLIP's
+    encode_text (causal 12-head attention, QuickGELU MLP, EOT-row gather, text projection, L2 normalisation), and the
+    token-axis / n_repeat handling of `encode`.  Parity is against the oracle only: the `clip` package is absent (oracle header)."""
+    from frido.modules.encoders.modules import FrozenCLIPTextEmbedder
+    from frido_amd.holders import CLIP_TEXT_ARCH
+    from frido_amd.synth import fill_tensor
+    from oracle.clip_text import clip_encode_text
+    kw = dict(version=arch) if isinstance(arch, str) else dict(arch=arch)
+    a = CLIP_TEXT_ARCH[arch] if isinstance(arch, str) else arch
+    m = fill_module(FrozenCLIPTextEmbedder(n_repeat=3, **kw), "cond_stage_model.").cuda()
+    tokens = _clip_tokens(3, a[1], a[2], 5)
+    sd = {"cond_stage_model." + k: torch.from_numpy(fill_tensor("cond_stage_model." + k, v.shape)) for k, v in m.state_dict().items()}
+    ref = clip_encode_text(sd, tokens, heads=a[4])
+    z = m(tokens.cuda())
+    assert z.shape == ref.shape and _rel(z, ref) < 3e-4
+    assert float((z.norm(dim=1) - 1).abs().max()) < 1e-5
+    c = m.encode(tokens.cuda())
+    assert c.shape == (3, 3, a[0]) and torch.equal(c[:, 0], c[:, 2]) and _rel(c[:, 1], ref) < 3e-4
+    m.normalize = False
+    m.invalidate()
+    assert _rel(m(tokens.cuda()), clip_encode_text(sd, tokens, heads=a[4], normalize=False)) < 3e-4
 
 
 def test_full_pipeline_with_cond_stage_and_get_input():
@@ -502,7 +541,65 @@ def _e2e_report(tag, model, g, run, samples, embed):
     rep["forced_pix_max"] = float((forced[:, :, ::ss, ::ss].cpu() - torch.from_numpy(g[f"{run}_img"])).abs().max())
     rep["forced_sum_rel"] = abs(float(forced.double().sum()) - float(g[f"{run}_img_sum"])) / float(g[f"{run}_img_abs_sum"])
     print(f"E2E {tag}: decoder on the reference's latent and codes: max-abs {rep['forced_pix_max']:.3e}, sum rel {rep['forced_sum_rel']:.3e}")
+    _record(tag, rep)
     return rep
+
+
+_E2E = {}
+
+
+def _record(tag, rep):
+    """The end-to-end error records are WRITTEN BY THE TESTS (gpurun_out/e2e_error.json under the repo root, merged back by
+    gpurun; the copy judged is profiles/r03_e2e_error.json) instead of being re-typed from the log."""
+    import json
+    _E2E[tag] = {k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in rep.items()}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "e2e_error.json")
+    blob = {}
+    if os.path.exists(path):
+        try:
+            blob = json.load(open(path))
+        except ValueError:
+            blob = {}
+    blob.update(_E2E)
+    with open(path, "w") as f:
+        json.dump(blob, f, indent=1, sort_keys=True)
+
+
+def _oracle_flip_counts(g, run, S, threads=(1, 16)):
+    """What the ORACLE itself does on this fixture: the CPU restatement (fp32 torch) re-run at different intra-op thread counts
+    (torch's conv / GEMM kernels change their summation order with the thread count) vs the reference's recorded run -- the
+    number of VQ codes that flip between two fp32 CPU runs of the same algorithm is the yardstick for the HIP path's flips."""
+    import sys
+    from golden_cfg import BERT_FULL  # noqa: F401
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import samplers as S_
+    from oracle.unet import unet_forward
+    from oracle.vqgan import vq_decode
+    from frido_amd.models import PyUNetModel, VQModelInterface
+    from frido_amd.synth import fill_tensor
+    usd = {"model.diffusion_model." + k: torch.from_numpy(fill_tensor("model.diffusion_model." + k, v.shape))
+           for k, v in PyUNetModel(**UNET_FULL).state_dict().items()}
+    vsd = {"first_stage_model." + k: torch.from_numpy(fill_tensor("first_stage_model." + k, v.shape))
+           for k, v in VQModelInterface(**VQ_FULL, lossconfig=dict(target="taming.modules.losses.DummyLoss")).state_dict().items()}
+    ac = S_.alphas_cumprod_f32(S_.make_betas())
+    am = lambda x, t, cond, s: unet_forward(usd, UNET_FULL, x, t, cond, s)
+    res = {}
+    keep = torch.get_num_threads()
+    for nt in threads:
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        torch.manual_seed(23)
+        out, _ = S_.ddim_sample(am, ac, S, (1, 6, 64, 64), torch.from_numpy(g["c"]), [3, 3], [3, 3], 2, eta=1.0, log_every_t=10 ** 9)
+        _, codes = vq_decode(vsd, VQ_FULL, S_.decode_first_stage(lambda z: z, out, g["scale_factor"].tolist(), [3, 3]), return_code=True)
+        code = np.stack([cd.numpy() for cd in codes]).reshape(g[f"{run}_code"].shape)
+        res[f"threads_{nt}"] = dict(latent_rel=float((out - torch.from_numpy(g[f"{run}_samples"])).abs().max() / np.abs(g[f"{run}_samples"]).max()),
+                                    vq_flips=int((code != g[f"{run}_code"]).sum()), codes=int(code.size))
+    torch.set_num_threads(keep)
+    return res
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
@@ -524,6 +621,11 @@ def test_config1_full_width_end_to_end(run, S, precision):
     assert abs(rec.sum - float(g[f"{run}_noise_sum"])) < 1e-6 * rec.n, "torch CPU generator stream differs from the fixture's"
     assert len(inter["x_inter"]) == int(g[f"{run}_nx"])
     rep = _e2e_report(f"config1/{run}/{precision}", model, g, run, samples, [3, 3])
+    if precision == "bf16x3" and run == "ddim4":
+        # yardstick for the flip allowance below: the oracle (fp32 on the CPU) against the same fixture at 1 and 16 threads
+        rep["oracle_vs_reference"] = _oracle_flip_counts(g, run, S)
+        print(f"E2E config1/{run}: oracle's own code flips vs the reference's run: {rep['oracle_vs_reference']}")
+        _record(f"config1/{run}/{precision}", rep)
     if precision == "bf16x3":
         # north star: <= 1e-3 max-abs on decoded pixels.  Unconditional for the decoder (reference latent + codes); end to end
         # it holds wherever no VQ code flipped -- one flipped code (a discontinuity) reaches every pixel through the decoder's
@@ -605,6 +707,67 @@ def test_config5_three_scale_512_forward_and_decode():
     assert abs(float(forced.double().sum()) - float(gv["dec_img_sum"])) < 2e-4 * float(gv["dec_img_abs_sum"])
 
 
+def test_engine_cache_eviction_releases_persistent_buffers():
+    """samplers.ENGINE_CACHE_SIZE bounds the compiled engines per denoiser; an evicted engine owns its plans' persistent buffers
+    (Builder.persist_scope), so HBM plateaus when a process cycles through more sampling signatures than the cache holds."""
+    import gc
+    from frido.models.diffusion.ddim import DDIMSampler
+    from frido_amd.samplers import ENGINE_CACHE_SIZE
+    model = _frido(UNET_SMALL, VQ_SMALL)
+    mems = []
+    for nctx in range(3, 3 + ENGINE_CACHE_SIZE + 5):
+        c = torch.randn(2, nctx, 64, device="cuda")
+        DDIMSampler(model).sample(S=2, batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=1.0, verbose=False,
+                                  noise="philox")
+        torch.cuda.synchronize()
+        gc.collect()
+        mems.append(torch.cuda.memory_allocated())
+    rt = model.model.diffusion_model.runtime()
+    assert len(rt._sampler_engines) == ENGINE_CACHE_SIZE
+    assert max(mems[ENGINE_CACHE_SIZE + 1:]) <= max(mems[:ENGINE_CACHE_SIZE + 1]) * 1.03 + (1 << 20), mems
+
+
+def test_config5_three_stage_multistep_at_true_size():
+    """BASELINE config 5, MULTI-STEP at its true size (tests/golden/make_golden.py sampler_512): the three-stage DDIM loop
+    (S = 2, eta = 1: six denoiser forwards, both hand-offs incl. the 4x4 block mean of stage 0, ddim.py:146-149,177-185) on the
+    9 x 128 x 128 latent with 92 context tokens, then the 512 x 512 decode -- against the reference's own CPU run on the same
+    torch noise stream."""
+    from frido.models.diffusion.ddim import DDIMSampler
+    from golden_cfg import UNET_512, VQ_512
+    g = golden("sampler_512")
+    model = _frido(UNET_512, VQ_512, precision="bf16x3")
+    c = torch.from_numpy(g["c"]).cuda()
+    rec = _Rec()
+    torch.manual_seed(23)
+    samples, inter = DDIMSampler(model).sample(S=2, batch_size=1, shape=(9, 128, 128), conditioning=c, num_stage=3, eta=1.0,
+                                               verbose=False, log_every_t=int(g["ddim2_args"][3]), noise=rec)
+    assert rec.n == int(g["ddim2_noise_n"]) and abs(rec.sum - float(g["ddim2_noise_sum"])) < 1e-6 * rec.n
+    assert len(inter["x_inter"]) == int(g["ddim2_nx"])
+    rep = _e2e_report("config5/ddim2x3stages/bf16x3", model, g, "ddim2", samples, [3, 3, 3])
+    assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+    if rep["vq_flip_rate"] == 0:
+        assert rep["pix_max"] < 1e-3
+
+
+def test_config2_step_count_ddim200_end_to_end():
+    """BASELINE config 2's step count: layout2i f8f4 at full width, DDIM-200 eta = 1 x 2 stages (400 graph replays) + decode at
+    B = 1, against the reference's own CPU run (tests/golden/make_golden.py sampler_ddim200) in the parity arithmetic."""
+    from frido.models.diffusion.ddim import DDIMSampler
+    g = golden("sampler_ddim200")
+    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3")
+    c = torch.from_numpy(g["c"]).cuda()
+    rec = _Rec()
+    torch.manual_seed(23)
+    samples, inter = DDIMSampler(model).sample(S=200, batch_size=1, shape=(6, 64, 64), conditioning=c, num_stage=2, eta=1.0,
+                                               verbose=False, log_every_t=int(g["ddim200_args"][3]), noise=rec)
+    assert rec.n == int(g["ddim200_noise_n"]) and abs(rec.sum - float(g["ddim200_noise_sum"])) < 1e-6 * rec.n
+    assert len(inter["x_inter"]) == int(g["ddim200_nx"])
+    rep = _e2e_report("config2-steps/ddim200/bf16x3", model, g, "ddim200", samples, [3, 3])
+    assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+    if rep["vq_flip_rate"] == 0:
+        assert rep["pix_max"] < 1e-3
+
+
 def test_bench_under_torchrun_takes_the_rccl_path_at_n1():
     """The driver launches bench.py with torch.distributed.run for N > 1; at N = 1 the same launch exercises the whole
     distributed path on one GPU: nccl (= RCCL) process group, contiguous shard with sample0, the all-gather of decoded
@@ -617,7 +780,7 @@ def test_bench_under_torchrun_takes_the_rccl_path_at_n1():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
                           "127.0.0.1", "--master-port", "29533", os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "1",
-                          "--warmup", "0", "--batch", "2", "--ddim-steps", "4", "--no-cpu-baseline", "--no-parity-mode"],
+                          "--warmup", "0", "--batch", "2", "--ddim-steps", "4", "--no-cpu-baseline", "--no-bf16-extra"],
                          capture_output=True, text=True, env=env, timeout=900, cwd=repo)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]

@@ -196,6 +196,22 @@ def test_512_three_scale_oracle():
 
 
 @pytest.mark.slow
+def test_512_three_stage_multistep_oracle():
+    """BASELINE config 5, multi-step at its true size: the oracle's 3-stage DDIM-2 loop on the 9 x 128 x 128 latent (both hand-offs,
+    incl. the 4 x 4 block mean of stage 0) vs the reference's run (tests/golden/make_golden.py sampler_512)."""
+    from golden_cfg import UNET_512
+    g = golden("sampler_512")
+    usd = synth_sd(unet_holder(UNET_512), "model.diffusion_model.")
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    am = lambda x, t, cond, s: unet_forward(usd, UNET_512, x, t, cond, s)
+    torch.manual_seed(23)
+    out, inter = S.ddim_sample(am, ac, 2, (1, 9, 128, 128), torch.from_numpy(g["c"]), [3, 3, 3], [3, 3, 3], 3, eta=1.0,
+                               log_every_t=int(g["ddim2_args"][3]))
+    assert len(inter["x_inter"]) == int(g["ddim2_nx"])
+    assert float((out - torch.from_numpy(g["ddim2_samples"])).abs().max()) < 2e-5 * float(np.abs(g["ddim2_samples"]).max())
+
+
+@pytest.mark.slow
 def test_full_width_ddim4_oracle():
     """BASELINE config 1 plumbing at DDIM-4: the real 32-layer cond stage, both stages at full width, decode."""
     from golden_cfg import BERT_FULL

@@ -2,7 +2,7 @@
 # A/B of an env switch that changes the TUNER's candidate set (each value gets its own tile cache), interleaved on one box:
 #   tools/ab_env_tuned.sh FRIDO_TUNE_BIG_SPLITK 0 1
 VAR=${1:?env var}; shift
-for v in "$@"; do env $VAR=$v FRIDO_TUNE_CACHE=/tmp/tune_${VAR}_$v.json python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1; done
+for v in "$@"; do env $VAR=$v FRIDO_TUNE_CACHE=/tmp/tune_${VAR}_$v.json python bench.py --retune --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1; done
 for i in 1 2 3; do
   for v in "$@"; do
     env $VAR=$v FRIDO_TUNE_CACHE=/tmp/tune_${VAR}_$v.json python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode 2>&1 | grep -v amdgpu.ids | tail -1 |

@@ -4,7 +4,7 @@
 #   tools/ab_lib_tuned.sh frido_amd/libfrido_hip_old.so frido_amd/libfrido_hip.so
 A=${1:?old lib}; B=${2:?new lib}
 for L in $A $B; do
-  FRIDO_LIB=$PWD/$L FRIDO_TUNE_CACHE=/tmp/tune_$(basename $L).json python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
+  FRIDO_LIB=$PWD/$L FRIDO_TUNE_CACHE=/tmp/tune_$(basename $L).json python bench.py --retune --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
 done
 for i in 1 2 3; do
   for L in $A $B; do
