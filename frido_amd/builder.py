@@ -15,6 +15,7 @@ ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample convs as four 2x2 phase convolutions
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
+GN_EPI_STATS = os.environ.get("FRIDO_GN_EPI_STATS", "1") != "0"   # GroupNorm partial sums from the producing GEMM's epilogue (bf16x3 f32 stream)
 ATTN_FLASH = os.environ.get("FRIDO_ATTN_FLASH", "1") != "0"       # flash-style kernel for long key sequences (flash.hip)
 # below this many keys the score matrix is small and the batched GEMM -> softmax -> GEMM chain fills the chip better than
 # one workgroup per 64 queries (measured at B = 16: 256 keys x d = 576: 37 us vs 49 us; 1024 keys x d = 384: 102 vs 82 us)
@@ -224,7 +225,8 @@ class Builder:
         geom = dict(Hs=H, Ws=W, Cin=cp, Hl=H, Wl=W, Ho=H, Wo=W, kh=kh, kw=kw, stride=1, pad=1, up_shift=0, dn_shift=0)
         res = self.f32(M, co)
         self.prog.gemm(M, co, kh * kw * cp, a, wop, ldb=kh * kw * cp + k2, conv=geom, bias=bsum.data_ptr(), out_f32=res.ptr, ldo=co,
-                       out_bf16=res.bf16, A2=raw, lda2=raw.K, K2=k2)
+                       out_bf16=res.bf16, A2=raw, lda2=raw.K, K2=k2, gn_part=self._parts_for(res, M, co))
+        self._parts_done(res)
         return res
 
     def up2_phase_weights(self, wname):
@@ -328,10 +330,45 @@ class Builder:
         if rowvec is not None:
             kw.update(rowvec=rowvec["ptr"], rows_per_vec=rowvec["rows_per_vec"], ldv=rowvec["ld"],
                       rowvec_step=rowvec.get("step"))
+        stream_out = out == "f32" or (isinstance(out, tuple) and out[0] == "f32" and isinstance(res, F32))
+        if stream_out and res.gn_part is not None:      # an existing activation is being overwritten: its old partial sums are stale
+            self.pool.release(res.gn_part)
+            res.gn_part = None
+        if stream_out and res.C == N:
+            kw["gn_part"] = self._parts_for(res, M, N, act=act, rowvec=rowvec, residual=residual,
+                                            up2=bool(conv and conv.get("up2_phase")))
         self.prog.gemm(M, N, K, a, wop, bias=bias, act=act, alpha=alpha, conv=conv, **kw)
+        if stream_out:
+            self._parts_done(res)
         return res
 
+    def _parts_for(self, res, M, N, *, act=0, rowvec=None, residual=None, up2=False):
+        """Partial-sum buffer for the GEMM about to write the f32 stream activation `res` (FridoGemm.gn_part), or None when the
+        launch does not take the store-from-registers f32 epilogue (mirror of the library's check in frido_gemm)."""
+        if not (GN_EPI_STATS and self.nsplit == 2 and not getattr(res, "bf16", True) and act == 0 and not up2 and N % 8 == 0 and M % 32 == 0):
+            return None
+        if rowvec is not None and (rowvec.get("rows_per_vec") or 0) < (1 << 29):
+            return None
+        if residual is not None and (getattr(residual, "bf16", False) or residual.C % 8):
+            return None
+        res.gn_part = self.pool.alloc((M // 32) * N * 8)
+        return res.gn_part.data_ptr()
+
+    def _parts_done(self, res):
+        """After Prog.gemm: the tuner may have chosen split-K, which drops the partial sums."""
+        if res is not None and getattr(res, "gn_part", None) is not None and not self.prog.ops[-1][1].gn_part:
+            self.pool.release(res.gn_part)
+            res.gn_part = None
+
     def gn_stats(self, x1, x2, B, HW):
+        p1, p2 = getattr(x1, "gn_part", None), getattr(x2, "gn_part", None) if x2 is not None else None
+        if p1 is not None and (x2 is None or p2 is not None) and HW % 32 == 0:
+            # statistics from the producers' per-channel partial sums (3 % of the tensor's bytes): one tiny launch
+            part = self.pool.alloc(B * 32 * 2 * 8)
+            self.prog.emit("FRIDO_OP_GN_STATS", x1=x1.ptr, C1=x1.C, x2=x2.ptr if x2 is not None else None,
+                           C2=x2.C if x2 is not None else 0, B=B, HW=HW, groups=32, nsplit_px=1, partials=part.data_ptr(), x_bf16=0,
+                           p1=p1.data_ptr(), p2=p2.data_ptr() if p2 is not None else None)
+            return part, 1
         S = max(1, min(64, HW // 4, max(1, 1024 // B)))     # ~1024 workgroups, at least 4 pixels each
         part = self.pool.alloc(B * S * 32 * 2 * 8)
         xb = getattr(x1, "bf16", False)

@@ -78,6 +78,8 @@ struct Geo {
     // bf16x3 (NS == 2) runs the software-pipelined virtual-k-step loop, in which every ring slot carries loads: two
     // 4-wave workgroups per CU (<= 80 KiB each) with 2-4 stages, or one 8-wave workgroup with what fits
     static constexpr int DX = 81920 / STAGE < 2 ? 2 : (81920 / STAGE > 4 ? 4 : 81920 / STAGE);
+    // (deeper rings with ONE workgroup per CU were measured on the small-M shapes, r03_x3_deep_ring_tiles.txt: no gain -- those
+    //  launches are bound by their fixed costs, not by stages in flight)
     static constexpr int D = NW == 8 ? (D8 < 2 ? 2 : D8) : (NS == 2 ? DX : ((4 * STAGE <= 98304) ? 4 : 3));
     static constexpr int SLABS = NW * 16 * (BN / 2 + 4) * 4;   // epilogue transpose slabs (one per wave)
     // + the bf16 residual sub-tile of every wave, DMA'd into the idle ring at the start of the epilogue (bf16 mode)
@@ -314,6 +316,11 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 });
             };
             if (has_res) fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            // GroupNorm statistics for free (r03): the values a lane stores are 8 consecutive channels of one pixel, so per-channel
+            // {sum, sum of squares} over a 32-row block = two slabs in registers + a 4-step reduction over the 16 pixel lanes;
+            // frido_gn_stats sums these partials (3 % of the tensor's bytes) instead of re-reading the tensor
+            float* const gnp = d.gn_part;
+            float gs[TJ][8], gq[TJ][8];
             static_for<0, TM>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i + 1 < TM) {
@@ -330,6 +337,32 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                         const float4 a = r0[i & 1][J], b = r1[i & 1][J];
                         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
                         v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                    }
+                    if (gnp) {
+                        const bool on = m < d.M && ncol0 + 32 * J < d.N;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float x = on ? v[e] : 0.f;
+                            if constexpr ((i & 1) == 0) { gs[J][e] = x; gq[J][e] = x * x; }
+                            else { gs[J][e] += x; gq[J][e] = fmaf(x, x, gq[J][e]); }
+                        }
+                        if constexpr ((i & 1) == 1) {       // a 32-row block is complete: reduce over the 16 pixel lanes, lane px_l == 0 stores
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                                for (int o = 1; o < 16; o <<= 1) {
+                                    gs[J][e] += __shfl_xor(gs[J][e], o, 64);
+                                    gq[J][e] += __shfl_xor(gq[J][e], o, 64);
+                                }
+                            }
+                            const int blk = (m0 + wm * WR + (i - 1) * 16) >> 5;
+                            if (px_l == 0 && ncol0 + 32 * J < d.N && (blk << 5) < d.M) {
+                                float* o = gnp + ((int64_t)blk * d.N + ncol0 + 32 * J) * 2;
+#pragma unroll
+                                for (int e = 0; e < 8; e += 2)
+                                    *reinterpret_cast<float4*>(o + 2 * e) = make_float4(gs[J][e], gq[J][e], gs[J][e + 1], gq[J][e + 1]);
+                            }
+                        }
                     }
                     if (m < d.M && ncol0 + 32 * J < d.N) {
                         if (d.out_f32) {
@@ -1886,6 +1919,13 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     if (d.geglu) {
         FRIDO_REQUIRE((d.N & 31) == 0 && d.out_op && !d.out_f32 && d.batch == 1 && d.splitk <= 1 && !d.residual && !d.rowvec,
                       "geglu epilogue: N % 32 == 0, operand output only, no split-K / residual / rowvec");
+    }
+    if (d.gn_part) {
+        FRIDO_REQUIRE(d.nsplit == 2 && d.out_f32 && !d.out_bf16 && !d.out_op && d.act == FRIDO_ACT_NONE && !d.row_bias && !d.geglu &&
+                          !d.up2_phase && d.splitk <= 1 && d.batch == 1 && !(d.flags & 18) && (d.N & 7) == 0 && (d.M & 31) == 0 &&
+                          ((d.ldo | d.ldr | d.ldv | d.of_bs | d.res_bs) & 7) == 0 && !(d.residual && d.res_bf16) &&
+                          (!d.rowvec || d.rows_per_vec >= (1 << 29)),
+                      "gn_part needs the store-from-registers f32 epilogue (see frido_hip.h)");
     }
     if (d.splitk > 1) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");

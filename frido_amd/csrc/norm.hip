@@ -89,6 +89,45 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
     }
 }
 
+// GroupNorm statistics from the PRODUCERS' per-channel partial sums (FridoGemm.gn_part: {sum, sumsq} per 32-row block and
+// channel): grid (B), 8 lanes per group walk its (block, channel) items in a fixed order, doubles from the first add on.
+__global__ __launch_bounds__(256) void gn_stats_parts_kernel(const FridoGnStats d) {
+    const int C = d.C1 + d.C2, cpg = C / d.groups;
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);           // one wave per (sample, group)
+    if (wg >= d.B * d.groups) return;
+    const int b = wg / d.groups, g = wg - b * d.groups;
+    const int nblk = d.HW >> 5, items = nblk * cpg;
+    double s = 0.0, q = 0.0;
+    // item idx = (block k, channel of the group): 4 independent loads in flight per lane, summed in index order
+    for (int i0 = lane; i0 < items; i0 += 256) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + 64 * u;
+            v[u] = make_float2(0.f, 0.f);
+            if (idx < items) {
+                const int k = idx / cpg, c = g * cpg + (idx - k * cpg);
+                const int64_t blk = (int64_t)b * nblk + k;
+                v[u] = c < d.C1 ? *reinterpret_cast<const float2*>(d.p1 + (blk * d.C1 + c) * 2)
+                                : *reinterpret_cast<const float2*>(d.p2 + (blk * d.C2 + (c - d.C1)) * 2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) {
+        double* out = d.partials + ((int64_t)b * d.groups + g) * 2;
+        out[0] = s;
+        out[1] = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GroupNorm apply: grid (blocks_per_image, B); prologue turns the partials into {mean, rstd}.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
@@ -359,6 +398,129 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const FridoGnApply d, int 
     }
 }
 
+// One-launch GroupNorm for the F32 stream of the bf16x3 (parity) mode: the same decomposition (workgroup = one sample x one
+// chunk of whole groups, the [HW][Cc] slice read ONCE into registers), f32 input / f32 SPADE maps, hi + lo operand planes
+// out.  r03: in parity mode every GroupNorm was two launches (gn_stats + gn_apply) plus a partials round trip, 122 launches per
+// denoiser forward; on the 16x16 and 8x8 planes those launches are pure latency (7-9 us each for a few hundred KB).
+// f32 slices: x + gamma + beta of 4 vectors = 96 VGPRs (3 vectors in the 1024-thread form, whose waves get 128 registers); larger
+// slices take more threads per workgroup instead of more registers per lane
+template <int NT, int GNF32_MAXV>
+__global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, int Cc) {
+    __shared__ double s_red[NT / 64][8];
+    __shared__ float s_mean[4], s_rstd[4];
+    const int C = d.C1 + d.C2, cpg = C / d.groups;
+    const int t = threadIdx.x, b = blockIdx.y, lane = t & 63, wave = t >> 6;
+    const int c0 = blockIdx.x * Cc;
+    const int vpp = Cc >> 3;                              // 8-channel vectors per pixel
+    const int ppi = NT / vpp;                             // pixels per sweep
+    const int cv = t % vpp, pl = t / vpp;
+    const bool live = pl < ppi;
+    const int c = c0 + cv * 8;
+    const float* src;
+    int ldx;
+    if (c < d.C1) { src = d.x1 + c; ldx = d.C1; }
+    else { src = d.x2 + (c - d.C1); ldx = d.C2; }
+    src += (int64_t)b * d.HW * ldx;
+    int gi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gi[e] = (cv * 8 + e) / cpg;
+    float xv[GNF32_MAXV][8];
+    float cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNF32_MAXV; ++k) {
+        const int p = pl + k * ppi;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bq = a;
+        if (live && p < d.HW) {
+            a = *reinterpret_cast<const float4*>(src + (int64_t)p * ldx);
+            bq = *reinterpret_cast<const float4*>(src + (int64_t)p * ldx + 4);
+        }
+        xv[k][0] = a.x; xv[k][1] = a.y; xv[k][2] = a.z; xv[k][3] = a.w; xv[k][4] = bq.x; xv[k][5] = bq.y; xv[k][6] = bq.z; xv[k][7] = bq.w;
+    }
+#pragma unroll
+    for (int k = 0; k < GNF32_MAXV; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs[e] += xv[k][e]; cq[e] = fmaf(xv[k][e], xv[k][e], cq[e]); }
+    // SPADE gamma / beta do not depend on the statistics: fetch them now, under the reduction
+    float4 gv[GNF32_MAXV][2], bv[GNF32_MAXV][2];
+    if (d.gamma) {
+#pragma unroll
+        for (int k = 0; k < GNF32_MAXV; ++k) {
+            const int p = pl + k * ppi;
+            if (live && p < d.HW) {
+                const int64_t o = ((int64_t)b * d.HW + p) * C + c;
+                gv[k][0] = *reinterpret_cast<const float4*>(d.gamma + o); gv[k][1] = *reinterpret_cast<const float4*>(d.gamma + o + 4);
+                bv[k][0] = *reinterpret_cast<const float4*>(d.beta + o); bv[k][1] = *reinterpret_cast<const float4*>(d.beta + o + 4);
+            }
+        }
+    }
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (gi[e] == g) { gs[g] += cs[e]; gq[g] += cq[e]; }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { gs[g] = wave_sum(gs[g]); gq[g] = wave_sum(gq[g]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { s_red[wave][g] = (double)gs[g]; s_red[wave][4 + g] = (double)gq[g]; }
+    }
+    __syncthreads();
+    if (t < 4) {
+        double sm = 0.0, sq = 0.0;
+        for (int w = 0; w < NT / 64; ++w) { sm += s_red[w][t]; sq += s_red[w][4 + t]; }
+        const double n = (double)d.HW * cpg;
+        const double mean = sm / n;
+        double var = sq / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[t] = (float)mean;
+        s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float r = s_rstd[gi[e]] * d.weight[c + e];
+        sc[e] = r;
+        sh[e] = d.bias[c + e] - s_mean[gi[e]] * r;
+    }
+#pragma unroll
+    for (int k = 0; k < GNF32_MAXV; ++k) {
+        const int p = pl + k * ppi;
+        if (p >= d.HW) break;
+        const int64_t o = ((int64_t)b * d.HW + p) * C + c;
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fmaf(xv[k][e], sc[e], sh[e]);
+        if (d.gamma) {
+            const float4 g0 = gv[k][0], g1 = gv[k][1], b0 = bv[k][0], b1 = bv[k][1];
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = fmaf(y[e], 1.f + gg[e], be[e]);
+        }
+        if (d.act == FRIDO_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+        }
+        uint32_t h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+        *reinterpret_cast<u32x4*>(d.out_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        if (d.nsplit == 2)
+            *reinterpret_cast<u32x4*>(d.out_op + d.out_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        if (d.raw_op) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split_bf16(xv[k][e], h[e], l[e]);
+            *reinterpret_cast<u32x4*>(d.raw_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            if (d.nsplit == 2)
+                *reinterpret_cast<u32x4*>(d.raw_op + d.raw_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row cached in registers (C <= 1024).
 __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) {
@@ -534,6 +696,12 @@ extern "C" int frido_gn_stats(const FridoGnStats* d, frido_stream_t s) {
     FRIDO_REQUIRE((d->C1 & 3) == 0 && (d->C2 & 3) == 0 && C <= GN_MAXC, "channel counts must be multiples of 4, <= 4096");
     FRIDO_REQUIRE(d->B > 0 && d->HW > 0 && d->nsplit_px > 0, "empty");
     FRIDO_REQUIRE(d->C2 == 0 || d->x2, "x2 missing");
+    if (d->p1) {
+        FRIDO_REQUIRE(d->nsplit_px == 1 && (d->HW & 31) == 0 && d->groups <= 32 && (d->C2 == 0 || d->p2),
+                      "statistics from partial sums: nsplit_px == 1, HW % 32 == 0, <= 32 groups, p2 for the second tensor");
+        hipLaunchKernelGGL(gn_stats_parts_kernel, dim3((d->B * d->groups + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
+        return frido_check_launch("gn_stats(parts)");
+    }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(d->nsplit_px, d->B), dim3(256), 0, (hipStream_t)s, *d);
     return frido_check_launch("gn_stats");
 }
@@ -556,7 +724,10 @@ extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
 // Chunk width of the one-launch GroupNorm: the smallest run of whole groups that is a multiple of 8 channels; 0 if the op
 // does not qualify (then the caller uses gn_stats + gn_apply).
 extern "C" int frido_gn_fused_chunk(const FridoGnApply* d, int* nthreads) {
-    if (!d || !d->x_bf16 || (d->gamma && !d->gb_bf16) || d->nsplit != 1 || d->out_f32 || !d->out_op) return 0;
+    if (!d || d->out_f32 || !d->out_op) return 0;
+    const bool bf16_form = d->x_bf16 && (!d->gamma || d->gb_bf16) && d->nsplit == 1;      // bf16 stream -> one bf16 plane
+    const bool f32_form = !d->x_bf16 && (!d->gamma || !d->gb_bf16);                        // f32 stream -> hi (+ lo) planes
+    if (!bf16_form && !f32_form) return 0;
     if (((d->C1 | d->C2) & 7) || d->groups <= 0) return 0;
     const int C = d->C1 + d->C2;
     if (C % d->groups) return 0;
@@ -565,10 +736,10 @@ extern "C" int frido_gn_fused_chunk(const FridoGnApply* d, int* nthreads) {
     while (G <= 4 && (G * cpg) % 8) ++G;
     if (G > 4 || d->groups % G) return 0;
     const int Cc = G * cpg, vpp = Cc / 8;
-    for (int nt = 256; nt <= 256; nt *= 4) {
+    for (int nt = 256; nt <= (f32_form ? 1024 : 256); nt *= 2) {
         if (vpp > nt) continue;
         const int ppi = nt / vpp;
-        if ((d->HW + ppi - 1) / ppi <= GNF_MAXV) {
+        if ((d->HW + ppi - 1) / ppi <= (f32_form ? (nt == 1024 ? 3 : 4) : GNF_MAXV)) {
             if (nthreads) *nthreads = nt;
             return Cc;
         }
@@ -582,7 +753,10 @@ extern "C" int frido_gn_fused(const FridoGnApply* d, frido_stream_t s) {
     const int Cc = frido_gn_fused_chunk(d, &nt);
     FRIDO_REQUIRE(Cc > 0, "GroupNorm does not qualify for the one-launch kernel (use gn_stats + gn_apply)");
     const int C = d->C1 + d->C2;
-    hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
+    if (d->x_bf16) hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
+    else if (nt == 256) hipLaunchKernelGGL((gn_fused_f32_kernel<256, 4>), dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
+    else if (nt == 512) hipLaunchKernelGGL((gn_fused_f32_kernel<512, 4>), dim3(C / Cc, d->B), dim3(512), 0, (hipStream_t)s, *d, Cc);
+    else hipLaunchKernelGGL((gn_fused_f32_kernel<1024, 3>), dim3(C / Cc, d->B), dim3(1024), 0, (hipStream_t)s, *d, Cc);
     return frido_check_launch("gn_fused");
 }
 

@@ -118,6 +118,7 @@ class F32:
         self.rows, self.C, self.pool, self.bf16 = rows, C, pool, bf16
         self.K, self.lo, self.nsplit, self.batch = C, 0, 1, 1       # operand view (valid when bf16)
         self.buf = pool.alloc(rows * C * (2 if bf16 else 4))
+        self.gn_part = None       # per-channel partial sums written by the producing GEMM's epilogue (FridoGemm.gn_part), if any
 
     @property
     def ptr(self):
@@ -134,6 +135,9 @@ class F32:
         if self.buf is not None:
             self.pool.release(self.buf)
             self.buf = None
+        if self.gn_part is not None:
+            self.pool.release(self.gn_part)
+            self.gn_part = None
 
 
 class Alias:
@@ -218,7 +222,8 @@ class Prog:
     def gemm(self, M, N, K, A, B, *, batch=1, lda=None, ldb=None, a_bs=0, b_bs=0, a_lo=None, b_lo=None,
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
              residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
-             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0, A2=None, lda2=0, K2=0):
+             oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0, A2=None, lda2=0, K2=0,
+             gn_part=None):
         """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
         ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
@@ -245,12 +250,15 @@ class Prog:
             kw.update(out_f32=out_f32, of_bs=of_bs, ldo=ldo, out_bf16=int(out_bf16))
         if out_op is not None:
             kw.update(out_op=out_op, oo_bs=oo_bs, ldoo=ldoo, oo_lo=oo_lo)
+        if gn_part is not None:
+            kw["gn_part"] = gn_part
         self.emit("FRIDO_OP_GEMM", **kw)
         if not tile and self.device.type == "cuda":
             from . import tune
             st = self.ops[-1][1]
             st.tile, st.splitk = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
             if st.splitk > 1:
+                st.gn_part = None       # the split-K reduction kernel does not produce them (the consumer falls back to gn_stats)
                 # ops of the executor's side stream run CONCURRENTLY with main-stream ops: they get their own workspace
                 st.ws = tune.workspace(self.device, _lib.lib().frido_gemm_workspace_bytes(C.addressof(st)),
                                        self.ws_tag + (":s1" if self._sid else ""))

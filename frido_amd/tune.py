@@ -111,6 +111,7 @@ def best_tile(st, device, stream):
     t = G()
     C.memmove(C.addressof(t), C.addressof(st), C.sizeof(G))
     ns = st.nsplit
+    t.gn_part = None         # candidates are timed without the fused GroupNorm partial sums (split-K tiles cannot produce them)
     t.up2_phase = 0          # timed with in-order output rows: the scratch output is M x N, not the interleaved 4M x N
     if st.conv:
         a_elems = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin

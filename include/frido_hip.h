@@ -89,8 +89,14 @@ typedef struct FridoGemm {
     int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to `ws` [splitk][M][N] f32 and a
                                    second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
     float* ws;
+    float* gn_part;             /* optional (bf16x3 f32-stream outputs): per-channel partial {sum, sum of squares} of the STORED values
+                                   over every 32-row block, gn_part[((m / 32) * N + n) * 2 + {0, 1}], written by the store-from-
+                                   registers epilogue; frido_gn_stats (p1 / p2) turns them into GroupNorm statistics without
+                                   re-reading the tensor (pyunet.py:262-300: every GroupNorm input is a conv / linear output).
+                                   Needs: nsplit 2, f32 output only, no activation / row bias / GEGLU / split-K / batching /
+                                   upsample phases, N % 8 == 0, M % 32 == 0 (rejected otherwise) */
     int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 (BK 32);
-                                   7 = 256x128, 8 = 256x256 (8 waves, bf16 mode);
+                                   7 = 256x128 (8 waves), 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64), 17 = 256x128 with BK 64 */
     int32_t flags;              /* A/B switches (0 = defaults): bit 0 = do not stage the bf16 residual tile through LDS in the
                                    epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
@@ -109,6 +115,8 @@ typedef struct FridoGnStats {
     int32_t B, HW, groups, nsplit_px;
     double* partials;
     int32_t x_bf16;             /* 1: x1 / x2 are bf16 */
+    const float* p1; const float* p2;   /* both non-null (p2 only when C2 > 0): do not read x1 / x2 -- sum the producers' per-channel
+                                   partial sums instead (FridoGemm.gn_part: [B * HW / 32][C1 or C2][2]); nsplit_px must be 1 */
 } FridoGnStats;
 
 /* GroupNorm apply (+ SPADE modulation + SiLU) -> operand tensor.

@@ -303,6 +303,42 @@ def test_groupnorm_apply(C1, C2, HW, spade):
     assert _relerr(raw.to_f32().cpu(), xc.reshape(B * HW, C)) < 2e-5
 
 
+@pytest.mark.parametrize("C1,C2,H,tile", [(192, 0, 64, 0), (384, 0, 32, 7), (192, 192, 32, 1), (384, 192, 32, 2), (96, 0, 32, 6)])
+def test_groupnorm_statistics_from_the_conv_epilogue(C1, C2, H, tile, monkeypatch):
+    """bf16x3 stream: the convolutions that PRODUCE a GroupNorm's input(s) leave per-channel partial sums of the values they store
+    (FridoGemm.gn_part, 32-row blocks); gn_stats sums those instead of re-reading the tensor(s).  Checked against
+    F.group_norm of the f32 convolution outputs, single tensor and the virtual concat of two producers, on several tiles."""
+    from frido_amd import tune
+    monkeypatch.setattr(tune, "ENABLED", False)      # (the tuner may pick split-K on these small problems, which drops the partial sums)
+    B, W, Cin = 2, H, 64
+    b = _builder(2, {"a.weight": (_t("ea", C1, Cin, 3, 3) / np.sqrt(9 * Cin)).cuda(), "a.bias": _t("eab", C1).cuda(),
+                     "b.weight": (_t("eb", max(C2, 8), Cin, 3, 3) / np.sqrt(9 * Cin)).cuda(), "b.bias": _t("ebb", max(C2, 8)).cuda(),
+                     "n.weight": (1 + 0.1 * _t("enw", C1 + C2)).cuda(), "n.bias": (0.1 * _t("enb", C1 + C2)).cuda()})
+    x = _t("ex", B * H * W, Cin)
+    xd = x.cuda()
+    a_op = b.pack(xd.data_ptr(), 1, B * H * W, Cin, 0, Cin)
+    y1 = b.conv(a_op, B, H, W, "a")
+    if tile:
+        b.prog.ops[-1][1].tile = tile
+    assert y1.gn_part is not None and b.prog.ops[-1][1].gn_part
+    y2 = None
+    if C2:
+        y2 = b.conv(a_op, B, H, W, "b")
+        assert y2.gn_part is not None
+    n_before = len(b.prog.ops)
+    o, _ = b.groupnorm(y1, y2, B, H * W, "n", 1e-5, act=2)
+    kinds = [k for k, _ in b.prog.ops[n_before:]]
+    from frido_amd import _lib
+    assert kinds == [_lib.OP_KINDS["FRIDO_OP_GN_STATS"], _lib.OP_KINDS["FRIDO_OP_GN_APPLY"]] and b.prog.ops[n_before][1].p1
+    _run(b)
+    xi = x.view(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xi, b.w["a.weight"].cpu(), b.w["a.bias"].cpu(), padding=1)
+    if C2:
+        ref = torch.cat([ref, F.conv2d(xi, b.w["b.weight"].cpu(), b.w["b.bias"].cpu(), padding=1)], dim=1)
+    ref = F.silu(F.group_norm(ref, 32, b.w["n.weight"].cpu(), b.w["n.bias"].cpu(), 1e-5)).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+    assert _relerr(o.to_f32().cpu(), ref) < 5e-5
+
+
 @pytest.mark.parametrize("C1,C2,HW", [(960, 0, 64), (576, 0, 256), (384, 0, 1024), (192, 0, 4096), (960, 960, 64), (960, 576, 256),
                                       (192, 192, 4096), (64, 0, 256), (96, 32, 64), (576, 0, 4096)])
 @pytest.mark.parametrize("spade", [False, True])
