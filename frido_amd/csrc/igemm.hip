@@ -32,6 +32,9 @@
 #ifndef FRIDO_ABLATE
 #define FRIDO_ABLATE 0
 #endif
+#ifndef FRIDO_X3_PIPE_ALL
+#define FRIDO_X3_PIPE_ALL 0      // 1: also run the six-n-tile bf16x3 tiles (128 x 192, 64 x 192) on the virtual-k-step loop
+#endif
 
 namespace {
 
@@ -661,7 +664,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     int64_t a_off[JA];
     unsigned a_mask[JA];
     const bool resample = CONV && (d.up_shift | d.dn_shift) != 0;
-    int a_b[JA], a_oy[JA], a_ox[JA];
+    int a_pos[JA];                       // (image << 20) | (oy << 10) | ox of this row's output pixel: only the resampling convs read it back
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
         const int row = (wave + NW * j) * CHR + lrow;
@@ -672,7 +675,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             const int hw = d.Ho * d.Wo;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-            a_b[j] = b; a_oy[j] = oy; a_ox[j] = ox;
+            a_pos[j] = (b << 20) | (oy << 10) | ox;
             unsigned mask = 0;
             for (int ty = 0; ty < d.kh; ++ty)
                 for (int tx = 0; tx < d.kw; ++tx) {
@@ -685,13 +688,6 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             m = m < d.M ? m : d.M - 1;      // rows past M are clamped (their outputs are masked)
             a_off[j] = (int64_t)m * d.lda * ((FRIDO_ABLATE & 16) ? 2 : 1) + lq * 8;
         }
-    }
-    int64_t a2_off[JA];
-#pragma unroll
-    for (int j = 0; j < JA; ++j) {
-        int m = m0 + (wave + NW * j) * CHR + lrow;
-        m = m < d.M ? m : d.M - 1;
-        a2_off[j] = (int64_t)m * d.lda2 + lq * 8;
     }
     const frido_bf16* __restrict__ A2b = d.A2;
     const int nk1 = d.K / BK;                 // k-tiles of the primary A operand
@@ -733,7 +729,9 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         if (ktn >= nk1) {               // appended dense operand (fused 1x1 skip conv): runs to the end of K
 #pragma unroll
             for (int j = 0; j < JA; ++j) {
-                aptr[j] = A2b + a2_off[j] + (int64_t)(ktn - nk1) * BK;
+                int m2 = m0 + (wave + NW * j) * CHR + lrow;          // (recomputed here: once per launch, nothing to keep live)
+                m2 = m2 < d.M ? m2 : d.M - 1;
+                aptr[j] = A2b + (int64_t)m2 * d.lda2 + lq * 8 + (int64_t)(ktn - nk1) * BK;
                 astep[j] = BK;
             }
             alo_cur = d.a2_lo;
@@ -761,9 +759,10 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 const bool ok = (a_mask[j] >> tap) & 1u;
                 int64_t off;
                 if (resample) {   // Upsample / SPADE-resize convs: source pixel = ((iy >> up) << dn, (ix >> up) << dn)
-                    const int iy = a_oy[j] * d.stride + ky - pady, ix = a_ox[j] * d.stride + kx - padx;
+                    const int a_b_ = a_pos[j] >> 20, a_oy_ = (a_pos[j] >> 10) & 1023, a_ox_ = a_pos[j] & 1023;
+                    const int iy = a_oy_ * d.stride + ky - pady, ix = a_ox_ * d.stride + kx - padx;
                     const int sy = (iy >> d.up_shift) << d.dn_shift, sx = (ix >> d.up_shift) << d.dn_shift;
-                    off = ((int64_t)(a_b[j] * d.Hs + sy) * d.Ws + sx) * d.Cin + kc + lq * 8;
+                    off = ((int64_t)(a_b_ * d.Hs + sy) * d.Ws + sx) * d.Cin + kc + lq * 8;
                 } else {
                     off = a_off[j] + ((int64_t)ky * ws + kx) * cin + kc;
                 }
@@ -929,7 +928,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         } else if (st + 1 == nsteps) {
             step(std::integral_constant<int, 0>{}, F_{}, st / KS, st % KS);
         }
-    } else if constexpr (NS == 2 && BN / 2 / 16 <= 4) {
+    } else if constexpr (NS == 2 && (BN / 2 / 16 <= 4 || FRIDO_X3_PIPE_ALL)) {
         // ---- bf16x3 main loop: software-pipelined over VIRTUAL k-steps (r03).  A stage holds the hi and lo planes of one 32-deep
         //      k-tile (= the LDS bytes of one BK = 64 bf16 stage); its product hi*hi + hi*lo + lo*hi is walked as three virtual
         //      k-steps, each TM x TN MFMAs on ONE pixel-fragment set and ONE weight-fragment set:

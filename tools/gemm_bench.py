@@ -63,6 +63,7 @@ def main():
         st.act = 100 - int(os.environ["NOEPI"])
     sk = int(os.environ.get("SPLITK", "1"))
     if sk > 1:
+        st.gn_part = None          # (split-K launches do not produce the fused GroupNorm partial sums)
         st.splitk = sk
         st.ws = tune.workspace(dev, sk * st.M * st.N * 4)
     for tile in tiles:
