@@ -694,10 +694,12 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     int64_t b_off[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        const int row = (wave + NW * j) * CHR + lrow;
+        constexpr bool BIL = (FRIDO_ABLATE & 512) && NS == 2;      // timing only: 8 rows x 128 B weight pieces
+        const int row = (wave + NW * j) * CHR + (BIL ? lane >> 3 : lrow);
         int n = n0 + (d.geglu ? row : chan_of_pos(row));      // LDS row `row` holds channel chan_of_pos(row): see tile_epilogue
         n = n < d.N ? n : d.N - 1;
-        b_off[j] = (int64_t)n * d.ldb * ((FRIDO_ABLATE & 16) && !CONV ? 2 : 1) + lq * 8;
+        if (BIL) n = n < d.N - 8 ? n : d.N - 9;      // (the "lo" piece reads 8 rows further down: stay inside the buffer)
+        b_off[j] = BIL ? (int64_t)n * d.ldb * 2 + (lane & 7) * 8 : (int64_t)n * d.ldb * ((FRIDO_ABLATE & 16) && !CONV ? 2 : 1) + lq * 8;
     }
 
     // k-tile range of this workgroup (split-K: gridDim.z slices)
@@ -709,8 +711,9 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     // keep the zero page's address in SGPRs (otherwise hipcc re-loads it from the GOT inside the k-loop)
     unsigned long long zero_addr = (unsigned long long)reinterpret_cast<const void*>(g_zero_page);
     asm volatile("" : "+s"(zero_addr));
-    const int64_t b_lo = AB64 ? (int64_t)16 * d.ldb : (FRIDO_ABLATE & 16) && !CONV ? 32 : d.b_lo;
+    const int64_t b_lo = ((FRIDO_ABLATE & 512) && NS == 2) ? (int64_t)16 * d.ldb : AB64 ? (int64_t)16 * d.ldb : (FRIDO_ABLATE & 16) && !CONV ? 32 : d.b_lo;
     constexpr int KADV = (FRIDO_ABLATE & 16) && !CONV ? 2 * BK : BK;      // elements a dense source pointer advances per k-tile
+    constexpr int KADVB = ((FRIDO_ABLATE & 512) && NS == 2) ? 2 * BK : KADV;
 
     // ---- incremental source pointers.  Inside one SEGMENT of the k-walk (the channel chunks of one conv tap, the whole K of
     //      a dense operand, the appended A2 range) every piece just advances by BK elements per k-tile; the per-piece
@@ -720,7 +723,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     int astep[JA];                      // BK, or 0 for a piece parked on the zero page
     const frido_bf16* bptr[JB];
 #pragma unroll
-    for (int j = 0; j < JB; ++j) bptr[j] = Bb + b_off[j] + (int64_t)kt0 * KADV;
+    for (int j = 0; j < JB; ++j) bptr[j] = Bb + b_off[j] + (int64_t)kt0 * KADVB;
     int ktn = kt0;                      // next k-tile to issue
     int seg_left = 0;                   // k-tiles left in the current segment
     int64_t alo_cur = d.a_lo;           // hi -> lo plane distance of the operand the segment reads
@@ -815,7 +818,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
             __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
             if (NS == 2)
                 __builtin_amdgcn_global_load_lds((gptr_t)(bptr[j] + b_lo), (lptr_t)(sb + PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
-            bptr[j] += KADV;
+            bptr[j] += KADVB;
         }
         advance();
     };
@@ -994,7 +997,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 #pragma unroll
             for (int j = 0; j < JA; ++j) aptr[j] += astep[j];
 #pragma unroll
-            for (int j = 0; j < JB; ++j) bptr[j] += KADV;
+            for (int j = 0; j < JB; ++j) bptr[j] += KADVB;
             issue_end();
         };
         // (ablation 256: waves 4..7 of an 8-wave workgroup take the refill's pieces half a window later than waves 0..3)

@@ -90,21 +90,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
 }
 
 // GroupNorm statistics from the PRODUCERS' per-channel partial sums (FridoGemm.gn_part: {sum, sumsq} per 32-row block and
-// channel): grid (B), 8 lanes per group walk its (block, channel) items in a fixed order, doubles from the first add on.
+// channel): one workgroup per (sample, group) walks its (block, channel) items in a fixed order, doubles from the first add on.
 __global__ __launch_bounds__(256) void gn_stats_parts_kernel(const FridoGnStats d) {
+    __shared__ double s_red[4][2];
     const int C = d.C1 + d.C2, cpg = C / d.groups;
-    const int lane = threadIdx.x & 63;
-    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);           // one wave per (sample, group)
-    if (wg >= d.B * d.groups) return;
-    const int b = wg / d.groups, g = wg - b * d.groups;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x / d.groups, g = blockIdx.x - b * d.groups;      // one workgroup per (sample, group)
     const int nblk = d.HW >> 5, items = nblk * cpg;
     double s = 0.0, q = 0.0;
-    // item idx = (block k, channel of the group): 4 independent loads in flight per lane, summed in index order
-    for (int i0 = lane; i0 < items; i0 += 256) {
+    // item idx = (block k, channel of the group): up to 4 independent loads in flight per thread, summed in index order
+    for (int i0 = t; i0 < items; i0 += 1024) {
         float2 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int idx = i0 + 64 * u;
+            const int idx = i0 + 256 * u;
             v[u] = make_float2(0.f, 0.f);
             if (idx < items) {
                 const int k = idx / cpg, c = g * cpg + (idx - k * cpg);
@@ -121,10 +120,12 @@ __global__ __launch_bounds__(256) void gn_stats_parts_kernel(const FridoGnStats 
         s += __shfl_xor(s, o, 64);
         q += __shfl_xor(q, o, 64);
     }
-    if (lane == 0) {
+    if (lane == 0) { s_red[wave][0] = s; s_red[wave][1] = q; }
+    __syncthreads();
+    if (t == 0) {
         double* out = d.partials + ((int64_t)b * d.groups + g) * 2;
-        out[0] = s;
-        out[1] = q;
+        out[0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+        out[1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
     }
 }
 
@@ -699,7 +700,7 @@ extern "C" int frido_gn_stats(const FridoGnStats* d, frido_stream_t s) {
     if (d->p1) {
         FRIDO_REQUIRE(d->nsplit_px == 1 && (d->HW & 31) == 0 && d->groups <= 32 && (d->C2 == 0 || d->p2),
                       "statistics from partial sums: nsplit_px == 1, HW % 32 == 0, <= 32 groups, p2 for the second tensor");
-        hipLaunchKernelGGL(gn_stats_parts_kernel, dim3((d->B * d->groups + 3) / 4), dim3(256), 0, (hipStream_t)s, *d);
+        hipLaunchKernelGGL(gn_stats_parts_kernel, dim3(d->B * d->groups), dim3(256), 0, (hipStream_t)s, *d);
         return frido_check_launch("gn_stats(parts)");
     }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(d->nsplit_px, d->B), dim3(256), 0, (hipStream_t)s, *d);

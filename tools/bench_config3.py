@@ -20,7 +20,7 @@ from frido_amd.engine import require_gpu  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])      # bf16x3 = the arithmetic of the parity tests
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--plms-steps", type=int, default=100)
     ap.add_argument("--steps", type=int, default=2)

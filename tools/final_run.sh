@@ -1,17 +1,28 @@
 #!/bin/bash
-# End-of-round GPU run: full GPU test suite, then the bench lines of record (tile cache written to profiles/tune_cache.json).
+# End-of-round GPU run: full GPU test suite, then the bench lines of record.  The pinned tile cache (profiles/tune_cache.json) is
+# rewritten by the first bench invocation (--retune) and read-only afterwards.
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
 (time python -m pytest tests -m gpu -q -s --durations=10 > $OUT/final_gpu_tests.log 2>&1); tail -4 $OUT/final_gpu_tests.log
+cp $OUT/e2e_error.json $OUT/${TAG}_e2e_error.json 2>/dev/null
 rm -f profiles/tune_cache.json
-python bench.py --steps 3 --warmup 1 --cpu-ddim50 > $OUT/r02_bench_line.json 2> $OUT/r02_bench_line.err
+python bench.py --retune --steps 3 --warmup 1 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.err      # bf16x3 headline + bf16 extra + CPU baseline
 cp profiles/tune_cache.json $OUT/tune_cache.json
-python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity-mode > $OUT/r02_bench_line_repeat.json 2>/dev/null     # second process: pinned tiles, no tuning
+python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-bf16-extra > $OUT/${TAG}_bench_line_repeat.json 2>/dev/null     # second process: pinned tiles, no tuning
+python bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline --no-bf16-extra --retune > $OUT/${TAG}_bench_line_batch32.json 2>/dev/null   # config 4's per-GPU shard (own tiles; the cache gains its signatures)
+cp profiles/tune_cache.json $OUT/tune_cache.json
+python tools/bench_config3.py > $OUT/${TAG}_config3_line_bf16x3.json 2>/dev/null
+python tools/bench_config5.py > $OUT/${TAG}_config5_line_bf16x3.json 2>/dev/null
 python - <<'PY'
-import json
-for f in ("gpurun_out/r02_bench_line.json", "gpurun_out/r02_bench_line_repeat.json"):
-    d = json.loads([l for l in open(f) if l.startswith("{")][-1])
-    print(f, d["value"], d["unit"], d.get("parity_mode", {}).get("value"), d.get("loop_only_value"), d["roofline"]["frac"], d.get("cpu_baseline", {}).get("value"))
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r03_*line*.json")):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+    except Exception as e:
+        print(f, "unreadable", e); continue
+    print(f, d.get("value"), d.get("unit"), d.get("dtype"), (d.get("extra") or {}).get("bf16_throughput_mode", {}).get("value"),
+          d.get("loop_only_value"), (d.get("roofline") or {}).get("frac"), (d.get("cpu_baseline") or {}).get("value"))
 PY
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
