@@ -127,8 +127,8 @@ class Builder:
         return wop, bias.data_ptr()
 
     def chained_linear(self, a, a2, first, second, residual):
-        """y = second(first(a) + a2) + residual with both Linears in ONE GEMM: [a | a2] . [W_s W_f | W_s]^T + (W_s b_f + b_s).
-        bf16-stream mode only (a2 is a bf16 activation read as a second A operand along K)."""
+        """y = second(first(a) + a2) + residual with both Linears in ONE GEMM: [a | a2] . [W_s W_f | W_s]^T + (W_s b_f + b_s)
+        (a2 is read as a second A operand along K)."""
         key = ("chain", first, second)
         if key not in self._wcache:
             wf, ws = self.h64(first + ".weight"), self.h64(second + ".weight")
@@ -139,12 +139,16 @@ class Builder:
             w[:, k1:k1 + ws.shape[1]] = ws
             self._wcache[key] = (pack_matrix(self.to_dev(w), self.nsplit), self.to_dev(bias), k1, k2)
         wop, bias, k1, k2 = self._wcache[key]
-        assert getattr(a2, "bf16", False) and a.K == k1 and a2.C == k2, (a.K, k1, a2.C, k2)
+        # a2: a bf16 stream activation (bf16 mode), or an operand copy of the f32 stream (bf16x3 mode: the cross-attention kernel
+        # writes it next to the stream, see attention(also_op=True))
+        a2k = a2.C if getattr(a2, "bf16", False) else a2.K
+        assert a.K == k1 and a2k == k2, (a.K, k1, a2k, k2)
         M = a.rows * getattr(a, "batch", 1)
         res = self.f32(M, wop.rows)
         self.prog.gemm(M, wop.rows, k1, a, wop, ldb=k1 + k2, bias=bias.data_ptr(), residual=residual.ptr, ldr=residual.C,
                        res_bf16=getattr(residual, "bf16", False), out_f32=res.ptr, ldo=wop.rows, out_bf16=res.bf16,
-                       A2=a2, lda2=a2.C, K2=k2)
+                       A2=a2, lda2=a2k, K2=k2, gn_part=self._parts_for(res, M, wop.rows, residual=residual))
+        self._parts_done(res)
         return res
 
     def folded_qk_weight(self, q_name, k_name, side):
@@ -446,7 +450,8 @@ class Builder:
                        d0=d0, to_nchw=int(to_nchw))
 
     # ---- attention (single head, unfused: QK^T -> softmax -> PV on the MFMA GEMM) -----------------
-    def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0, bias_ptr=None, residual=None, stream=False):
+    def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0, bias_ptr=None, residual=None, stream=False,
+                  also_op=False):
         """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
         [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158).
         stream=True (the out projection is folded into vT): returns the residual-stream activation O + bias + residual."""
@@ -465,6 +470,11 @@ class Builder:
             if stream:
                 res = self.f32(B * Nq, d)
                 assert residual is None or getattr(residual, "bf16", False) == res.bf16
+                if also_op and small and not res.bf16:
+                    # the short-key kernel also leaves the stream values as an operand (hi / lo planes): returns (stream, operand)
+                    o = self.op(B * Nq, d)
+                    kw.update(out_op=o.ptr, out_lo=o.lo, ldo=d)
+                    res.op_copy = o
                 self.prog.emit(kind, out_act=res.ptr, ld_act=d, residual=residual.ptr if residual is not None else None,
                                ldr=residual.C if residual is not None else 0, bias=bias_ptr, act_bf16=int(res.bf16), **kw)
                 return res

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
             const int col = tb * 16 + oc;
             if (d.out_act) {                    // residual-stream form: O + bias + residual
                 const int64_t ro = (int64_t)(row0 + orow) * d.ldr + col, oo = (int64_t)(row0 + orow) * d.ld_act + col;
+                float keep[CPL];                // (r03) the same values once more as an operand, when out_op is given as well
 #pragma unroll
                 for (int i = 0; i < CPL / 4; ++i) {
                     float4 v = make_float4(src[i * 4], src[i * 4 + 1], src[i * 4 + 2], src[i * 4 + 3]);
@@ -202,6 +203,21 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                             make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
                     } else {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo + i * 4) = v;
+                    }
+                    keep[i * 4] = v.x; keep[i * 4 + 1] = v.y; keep[i * 4 + 2] = v.z; keep[i * 4 + 3] = v.w;
+                }
+                if (d.out_op) {                 // operand copy of the stream values (A2 of the chained FF2 + proj_out GEMM)
+                    frido_bf16* dst = d.out_op + (int64_t)(row0 + orow) * d.ldo + col;
+#pragma unroll
+                    for (int i = 0; i < CPL / 8; ++i) {
+                        uint32_t h[8], l[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) split_bf16(keep[i * 8 + e], h[e], l[e]);
+                        *reinterpret_cast<uint4*>(dst + i * 8) =
+                            make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                        if (NS == 2)
+                            *reinterpret_cast<uint4*>(dst + d.out_lo + i * 8) =
+                                make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
                     }
                 }
             } else {

@@ -16,6 +16,9 @@ from .arch import unet_arch
 from .builder import Builder, ACT_NONE, ACT_RELU, ACT_SILU
 from .engine import rup
 
+import os
+CHAIN_FF = os.environ.get("FRIDO_CHAIN_FF", "1") != "0"     # FF2 + proj_out of a transformer block as one GEMM (A/B switch)
+
 
 class UNetStagePlan:
     def __init__(self, b: Builder, cfg, *, B, H, W, nctx, stage, x_state, temb_rows, per_sample_t, step_ptr=None,
@@ -246,17 +249,23 @@ class UNetStagePlan:
         # --- cross-attention (K, V^T cached per sample)
         n2 = b.layernorm(h2, t + ".norm2")
         kc, vTc, bvo2 = self.kv[pre]            # kc = ctx (W_q^T W_k)^T: the query projection is folded into the cached keys
-        h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True)
+        chain = CHAIN_FF and C % 64 == 0       # proj_out(h3 + ff2(gg)) + x in ONE GEMM (needs h3 as an operand along K)
+        h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True, also_op=chain)
         n2.free()
         h2.free()
         # --- GEGLU feed-forward (attention.py:37-64)
         n3 = b.layernorm(h3, t + ".norm3")
         gg = b.linear_geglu(n3, t + ".ff.net.0.proj")
         n3.free()
-        if b.stream_bf16 and C % 64 == 0:
-            # proj_out(h3 + ff2(gg)) + x in one GEMM: ff2 and proj_out are both linear, h3 rides along as a second K range
-            out = b.chained_linear(gg, h3, t + ".ff.net.2", pre + ".proj_out", x)
+        h3op = h3 if b.stream_bf16 else getattr(h3, "op_copy", None)     # bf16 stream: the activation is its own operand
+        if chain and h3op is not None:
+            # ff2 and proj_out are both linear: [gg | h3] . [W_p W_f | W_p]^T + (W_p b_f + b_p) + x (weights folded in float64);
+            # in bf16x3 mode h3's operand copy comes from the cross-attention kernel's epilogue (r03: one launch and the h4
+            # round trip less per transformer block)
+            out = b.chained_linear(gg, h3op, t + ".ff.net.2", pre + ".proj_out", x)
             gg.free()
+            if h3op is not h3:
+                h3op.free()
             h3.free()
             return out
         h4 = b.linear(gg, t + ".ff.net.2", residual=h3, out="op")

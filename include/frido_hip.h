@@ -164,7 +164,8 @@ typedef struct FridoSoftmax {
  * [B*Nq] (ldo).  Nq % 16 == 0, d % 32 == 0, dv % 16 == 0, ldvt = Nk rounded up to 32.
  * With `out_act` set the result leaves as the residual stream instead of an operand:
  * out_act[row][c] = O[row][c] + bias[c] + residual[row][c] (f32, or bf16 when act_bf16) -- the form used when the
- * attention output projection has been folded into V (single head: W_o (P V) = P (V W_o^T)). */
+ * attention output projection has been folded into V (single head: W_o (P V) = P (V W_o^T)).  With BOTH out_act and out_op set
+ * (short-key kernel only) the stream values are additionally written as an operand (hi / lo planes, ldo). */
 typedef struct FridoAttnSmall {
     const frido_bf16* Q; int64_t q_lo; int32_t ldq;
     const frido_bf16* K; int64_t k_lo; int64_t k_bs; int32_t ldk;
