@@ -219,34 +219,42 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
         }
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
         {
-            // bf16 mode: fragments of step ks + 1 are fetched under the MFMAs of step ks; bf16x3 mode has no registers to
-            // spare for a second fragment set (hi + lo planes of Q alone are 2 D / 8 VGPRs)
-            constexpr int NB = NS == 1 ? 2 : 1;
+            // the fragments of step ks + 1 are fetched under the MFMAs of step ks.  (r03: in bf16x3 mode too -- the 4-wave form runs
+            // one wave per SIMD, which may use all 512 registers; before, every k-step paid a full LDS round trip and then three
+            // DEPENDENT MFMAs per accumulator: 160 us for the 77 GFLOP of a 32x32-plane self-attention.)
+            constexpr int NB = 2;
             bf16x8 kf[NB][2][NS];                  // [buffer][half][plane]
-            if constexpr (NB == 2) {
-                kf[0][0][0] = lds_read128(k_frag);
-                kf[0][1][0] = lds_read128(k_frag + 1024);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                kf[0][0][p] = lds_read128(k_frag + p * G::KPL);
+                kf[0][1][p] = lds_read128(k_frag + p * G::KPL + 1024);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if constexpr (NB == 2) {
-                    if (ks + 1 < KS) {
-                        kf[(ks + 1) & 1][0][0] = lds_read128(k_frag + (ks + 1) * 2048);
-                        kf[(ks + 1) & 1][1][0] = lds_read128(k_frag + (ks + 1) * 2048 + 1024);
-                        wait_lgkm<2>();
-                    } else {
-                        wait_lgkm<0>();
-                    }
-                } else {
+                if (ks + 1 < KS) {
 #pragma unroll
                     for (int p = 0; p < NS; ++p) {
-                        kf[0][0][p] = lds_read128(k_frag + p * G::KPL + ks * 2048);
-                        kf[0][1][p] = lds_read128(k_frag + p * G::KPL + ks * 2048 + 1024);
+                        kf[(ks + 1) & 1][0][p] = lds_read128(k_frag + p * G::KPL + (ks + 1) * 2048);
+                        kf[(ks + 1) & 1][1][p] = lds_read128(k_frag + p * G::KPL + (ks + 1) * 2048 + 1024);
                     }
+                    wait_lgkm<2 * NS>();
+                } else {
                     wait_lgkm<0>();
                 }
-                s0 = mma3<NS>(kf[ks & (NB - 1)][0], qf[ks], s0);
-                s1 = mma3<NS>(kf[ks & (NB - 1)][1], qf[ks], s1);
+                if constexpr (NS == 2) {
+                    // hi*lo, lo*hi, hi*hi of the two score fragments interleaved: consecutive MFMAs never share an accumulator
+                    const bf16x8(&ka)[2] = kf[ks & 1][0];
+                    const bf16x8(&kb)[2] = kf[ks & 1][1];
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1], qf[ks][0], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[1], qf[ks][0], s1, 0, 0, 0);
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0], qf[ks][1], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[0], qf[ks][1], s1, 0, 0, 0);
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0], qf[ks][0], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[0], qf[ks][0], s1, 0, 0, 0);
+                } else {
+                    s0 = mma3<NS>(kf[ks & 1][0], qf[ks], s0);
+                    s1 = mma3<NS>(kf[ks & 1][1], qf[ks], s1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (nxt) {
 #pragma unroll
@@ -301,25 +309,47 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
             __builtin_amdgcn_s_barrier();          // V^T_j visible; every wave has finished reading K_j
             if (j + 1 < ntiles) issue_k(j + 1);
         }
-        {
-            constexpr int NB = NS == 1 ? 2 : 1;
-            bf16x8 vf[NB][NS];
-            if constexpr (NB == 2) vf[0][0] = lds_read128(v_frag);
+        if constexpr (NS == 1) {
+            bf16x8 vf[2][NS];
+            vf[0][0] = lds_read128(v_frag);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                if constexpr (NB == 2) {
-                    if (c + 1 < CT) {
-                        vf[(c + 1) & 1][0] = lds_read128(v_frag + (c + 1) * 1024);
-                        wait_lgkm<1>();
-                    } else {
-                        wait_lgkm<0>();
-                    }
+                if (c + 1 < CT) {
+                    vf[(c + 1) & 1][0] = lds_read128(v_frag + (c + 1) * 1024);
+                    wait_lgkm<1>();
                 } else {
-#pragma unroll
-                    for (int p = 0; p < NS; ++p) vf[0][p] = lds_read128(v_frag + p * G::VPL + c * 1024);
                     wait_lgkm<0>();
                 }
-                o[c] = mma3<NS>(vf[c & (NB - 1)], pf, o[c]);
+                o[c] = mma3<NS>(vf[c & 1], pf, o[c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // bf16x3 (r03): output row fragments in PAIRS -- the next pair's hi / lo V^T fragments are fetched under this pair's six
+            // MFMAs, whose three product terms alternate between the two accumulators
+            static_assert(CT % 2 == 0, "output row fragments are processed in pairs");
+            bf16x8 vf[2][2][NS];                   // [buffer][fragment of the pair][plane]
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) vf[0][q][p] = lds_read128(v_frag + p * G::VPL + q * 1024);
+#pragma unroll
+            for (int c = 0; c < CT; c += 2) {
+                const int cur = (c >> 1) & 1;
+                if (c + 2 < CT) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p) vf[cur ^ 1][q][p] = lds_read128(v_frag + p * G::VPL + (c + 2 + q) * 1024);
+                    wait_lgkm<2 * NS>();
+                } else {
+                    wait_lgkm<0>();
+                }
+                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][1], pf[0], o[c], 0, 0, 0);
+                o[c + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][1], pf[0], o[c + 1], 0, 0, 0);
+                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][0], pf[1], o[c], 0, 0, 0);
+                o[c + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][0], pf[1], o[c + 1], 0, 0, 0);
+                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][0], pf[0], o[c], 0, 0, 0);
+                o[c + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][0], pf[0], o[c + 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
