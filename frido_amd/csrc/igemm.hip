@@ -63,15 +63,19 @@ __device__ __forceinline__ int xcd_item(int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BM, int BN, int NS, int BK>
+template <int BM, int BN, int NS, int BK, bool W8 = false>
 struct Geo {
-    static constexpr int WMW = BM >= 256 ? 4 : 2;           // waves along M (x 2 along N): 4 or 8 waves per workgroup
+    // waves along M (x 2 along N): 4 or 8 waves per workgroup.  W8 (r03, tile 18 = 128 x 192): EIGHT waves on a 128-row tile, wave
+    // tile 32 x 96 -- one workgroup of 8 waves per CU where 128 x 192 tiles give exactly 256 or 512 workgroups
+    static constexpr int WMW = (BM >= 256 || W8) ? 4 : 2;
     static constexpr int NW = WMW * 2, NT = NW * 64;
     static constexpr int ROWB = BK * 2;                     // bytes per LDS row
     static constexpr int CHR = 1024 / ROWB;                 // rows per 1-KiB LDS-DMA chunk (16 / 8)
-    static constexpr int JA = BM / (NW * CHR), JB = BN / (NW * CHR);   // chunks per wave per plane
-    static_assert(JA * NW * CHR == BM && JB * NW * CHR == BN, "tile not divisible into per-wave DMA chunks");
-    static constexpr int LPT = (JA + JB) * NS;              // LDS-DMA instructions per thread per k-tile
+    // 1-KiB chunks per wave per plane.  The weight panel may deal UNEVENLY: with JBR != 0 only waves 0 .. JBR - 1 carry chunk JB - 1
+    static constexpr int JA = BM / (NW * CHR), JB = (BN / CHR + NW - 1) / NW, JBR = (BN / CHR) % NW;
+    static_assert(JA * NW * CHR == BM && BN % CHR == 0, "tile not divisible into per-wave DMA chunks");
+    static constexpr int LPT = (JA + JB) * NS;              // LDS-DMA instructions per thread per k-tile (waves >= JBR: NS fewer)
+    static constexpr int LPT_L = JBR ? (JA + JB - 1) * NS : LPT;
     static constexpr int PLANE = (BM + BN) * ROWB;
     static constexpr int STAGE = NS * PLANE;
     // LDS ring depth.  4-wave tiles: 3-4 stages -- a deeper ring costs resident workgroups per CU, and on the U-Net's
@@ -612,9 +616,10 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
     }
 }
 
-template <int BM, int BN, int NS, bool CONV, int BK>
-__global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW == 8 ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
-    using G = Geo<BM, BN, NS, BK>;
+template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false>
+__global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK, W8>::NW == 8 ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
+    using G = Geo<BM, BN, NS, BK, W8>;
+    constexpr int JBR = G::JBR;
     constexpr int ROWB = G::ROWB, CHR = G::CHR, KS = BK / 32;
     constexpr int WM = G::WMW, WN = 2, NW = G::NW;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -695,7 +700,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         constexpr bool BIL = (FRIDO_ABLATE & 512) && NS == 2;      // timing only: 8 rows x 128 B weight pieces
-        const int row = (wave + NW * j) * CHR + (BIL ? lane >> 3 : lrow);
+        int row = (wave + NW * j) * CHR + (BIL ? lane >> 3 : lrow);
+        row = row < BN ? row : BN - 1;                            // (uneven dealing: this wave has no chunk j; never issued)
         int n = n0 + (d.geglu ? row : chan_of_pos(row));      // LDS row `row` holds channel chan_of_pos(row): see tile_epilogue
         n = n < d.N ? n : d.N - 1;
         if (BIL) n = n < d.N - 8 ? n : d.N - 9;      // (the "lo" piece reads 8 rows further down: stay inside the buffer)
@@ -815,9 +821,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
-            if (NS == 2)
-                __builtin_amdgcn_global_load_lds((gptr_t)(bptr[j] + b_lo), (lptr_t)(sb + PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+            if (JBR == 0 || j < JB - 1 || wave < JBR) {
+                __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+                if (NS == 2)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(bptr[j] + b_lo), (lptr_t)(sb + PLANE + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+            }
             bptr[j] += KADVB;
         }
         advance();
@@ -837,6 +845,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
     const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * ROWB;
     const unsigned b_frag = lds0 + BM * ROWB + (wn * (BN / WN) + frow) * ROWB;
 
+    static_assert(JBR == 0 || (NS == 2 && W8), "uneven weight-chunk dealing: bf16x3 8-wave 128 x 192 tile only");
     if constexpr (NS == 1 && BK == 64) {
         // ---- software-pipelined main loop (bf16 mode, BK = 64 tiles).  The fragments of k-step t+1 are read from LDS into a SECOND register set
         //      while the MFMAs of k-step t issue from the first: with one workgroup of 8 waves per CU (or two of 4) the waves
@@ -931,7 +940,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         } else if (st + 1 == nsteps) {
             step(std::integral_constant<int, 0>{}, F_{}, st / KS, st % KS);
         }
-    } else if constexpr (NS == 2 && (BN / 2 / 16 <= 4 || FRIDO_X3_PIPE_ALL)) {
+    } else if constexpr (NS == 2 && (BN / 2 / 16 <= 4 || W8 || FRIDO_X3_PIPE_ALL)) {
         // ---- bf16x3 main loop: software-pipelined over VIRTUAL k-steps (r03).  A stage holds the hi and lo planes of one 32-deep
         //      k-tile (= the LDS bytes of one BK = 64 bf16 stage); its product hi*hi + hi*lo + lo*hi is walked as three virtual
         //      k-steps, each TM x TN MFMAs on ONE pixel-fragment set and ONE weight-fragment set:
@@ -951,14 +960,20 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
         constexpr bool SPREAD = D >= 3;
         constexpr int NG = SPREAD ? 3 * TN : TN;                     // MFMA groups one refill is dealt over
         static_assert(D <= 6 && (D - 1) * G::LPT < 64, "vmcnt immediate");
+        const bool light = JBR != 0 && wave >= JBR;                  // this wave carries one weight chunk less per stage
+        auto wait_stages = [&](auto kc) {                            // at most K whole stages of this wave's loads may stay in flight
+            constexpr int K = decltype(kc)::value;
+            if (light) wait_vmcnt<K * G::LPT_L>();
+            else wait_vmcnt<K * G::LPT>();
+        };
         auto wait_younger = [&](int younger) {                       // stages issued after the one waited for (loads retire in order)
             switch (younger) {
                 case 0: wait_vmcnt<0>(); break;
-                case 1: wait_vmcnt<(D > 1 ? 1 : 0) * G::LPT>(); break;
-                case 2: wait_vmcnt<(D > 2 ? 2 : 0) * G::LPT>(); break;
-                case 3: wait_vmcnt<(D > 3 ? 3 : 0) * G::LPT>(); break;
-                case 4: wait_vmcnt<(D > 4 ? 4 : 0) * G::LPT>(); break;
-                default: wait_vmcnt<(D > 5 ? 5 : 0) * G::LPT>(); break;
+                case 1: wait_stages(std::integral_constant<int, (D > 1 ? 1 : 0)>{}); break;
+                case 2: wait_stages(std::integral_constant<int, (D > 2 ? 2 : 0)>{}); break;
+                case 3: wait_stages(std::integral_constant<int, (D > 3 ? 3 : 0)>{}); break;
+                case 4: wait_stages(std::integral_constant<int, (D > 4 ? 4 : 0)>{}); break;
+                default: wait_stages(std::integral_constant<int, (D > 5 ? 5 : 0)>{}); break;
             }
         };
 #pragma unroll
@@ -990,7 +1005,8 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 constexpr int j = idx - JA;
                 const frido_bf16* srcb = bptr[j] + (pl ? b_lo : 0);
                 if constexpr (FRIDO_ABLATE & 32) srcb = reinterpret_cast<const frido_bf16*>(zero_addr) + (lane & 3) * 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
+                if (JBR == 0 || j < JB - 1 || wave < JBR)
+                    __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + BM * ROWB + j * (NW * 1024)), 16, 0, 0);
             }
         };
         auto refill_end = [&]() {                                    // every piece of the stage is out: step the source pointers
@@ -1012,7 +1028,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK>::NT), (Geo<BM, BN, NS, BK>::NW
                 if constexpr (PRE) {
                     // stage kt + 1 must have landed; past this barrier every wave holds stage kt in registers: its slot is free
                     if constexpr (!(FRIDO_ABLATE & 4)) {
-                        if (kt + D - 1 < nk) wait_vmcnt<(D - 2) * G::LPT>();
+                        if (kt + D - 1 < nk) wait_stages(std::integral_constant<int, D - 2>{});
                         else wait_younger(nk - kt - 2);
                         __builtin_amdgcn_s_barrier();
                     }
@@ -1743,10 +1759,10 @@ void launch_splitk_reduce(const FridoGemm& d, hipStream_t s) {
     else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
 }
 
-template <int BM, int BN, int NS, bool CONV, int BK>
+template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false>
 int set_attr() {
-    constexpr int smem = Geo<BM, BN, NS, BK>::SMEM;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV, BK>),
+    constexpr int smem = Geo<BM, BN, NS, BK, W8>::SMEM;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV, BK, W8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         frido_set_error("igemm: cannot set dynamic LDS size %d", smem);
         return FRIDO_EHIP;
@@ -1754,12 +1770,12 @@ int set_attr() {
     return FRIDO_OK;
 }
 
-template <int BM, int BN, int NS, bool CONV, int BK>
+template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false>
 int launch(const FridoGemm& d, hipStream_t s) {
-    constexpr int smem = Geo<BM, BN, NS, BK>::SMEM;
+    constexpr int smem = Geo<BM, BN, NS, BK, W8>::SMEM;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const int sk = d.splitk > 1 ? d.splitk : 1;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK>::NT), smem, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK, W8>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK, W8>::NT), smem, s, d);
     if (sk > 1) {
         launch_splitk_reduce(d, s);
     }
@@ -1815,6 +1831,9 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         if (tile == 10) return launch_patch(d, 4, s);
     }
     if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
+    if constexpr (NS == 2) {
+        if (tile == 18) return launch<128, 192, NS, CONV, 32, true>(d, s);     // 128 x 192 on eight waves (bf16x3)
+    }
     if constexpr (NS == 1) {
         if (tile == 8) return launch<256, 256, NS, CONV, 32>(d, s);
     }
@@ -1856,6 +1875,7 @@ int frido_igemm_init() {
     FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 2, true, 32>() | set_attr<256, 128, 2, false, 32>();
+    rc |= set_attr<128, 192, 2, true, 32, true>() | set_attr<128, 192, 2, false, 32, true>();
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
           set_attr<256, 256, 1, false, 32>() | set_attr<256, 128, 1, true, 64>() | set_attr<256, 128, 1, false, 64>();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -163,7 +163,7 @@ def best_tile(st, device, stream):
         # tile 9 = patch-staged 3x3 kernel (igemm.hip patch_ok; the library rejects it when it does not apply)
         patch = (st.conv and st.nsplit == 1 and st.batch == 1 and st.kh == 3 and st.stride == 1 and not (st.up_shift or st.dn_shift)
                  and not st.up2_phase and st.M % 128 == 0 and st.M >= 4096 and st.N >= 96 and sk <= (st.Cin + st.K2) // 32)
-        big_tiles = (TILES8W if st.nsplit == 1 else (7,)) if big else ()      # bf16x3: the 256 x 128 tile only
+        big_tiles = (TILES8W if st.nsplit == 1 else (7, 18)) if big else ()      # bf16x3: 256 x 128 and the 8-wave 128 x 192
         for tile in TILES + (TILES64 if k64 else ()) + big_tiles + ((17,) if big and k64 else ()) + ((9, 10) if patch else ()):
             if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue
