@@ -321,7 +321,6 @@ def test_sampler_matches_reference_golden(name, ucfg, vcfg, run):
     err = (img.cpu() - ref_img).abs().amax(dim=1)
     frac_bad = float((err > 1e-3).float().mean())
     print(f"{name}/{run}: latent rel err {_rel(samples, g[f'{run}_samples']):.2e}, pixels off by > 1e-3: {100 * frac_bad:.3f} %")
-    assert frac_bad < 0.02, frac_bad
     # the decoder on the REFERENCE's latent with the codes the oracle (pinned to the reference) assigns: no VQ boundary left
     from oracle.vqgan import quantize
     from frido_amd.synth import fill_tensor
@@ -337,6 +336,14 @@ def test_sampler_matches_reference_golden(name, ucfg, vcfg, run):
     worst = float((forced.cpu() - ref_img).abs().max())
     print(f"{name}/{run}: decoder max-abs pixel err on the reference's latent and codes {worst:.2e}")
     assert worst < 1e-3
+    # end to end: the <= 1e-3 criterion is asserted STRICTLY whenever the HIP path's codes equal the reference's (its own latent
+    # may sit on the other side of a VQ decision boundary: then only the number of such codes is bounded)
+    flips = int(sum((np.asarray(code[i]).reshape(-1) != codes[i].reshape(-1)).sum() for i in range(len(codes))))
+    ncodes = int(sum(c_.size for c_ in codes))
+    if flips == 0:
+        assert float(err.max()) < 1e-3, float(err.max())
+    else:
+        assert flips <= max(1, int(2e-3 * ncodes)), (flips, ncodes)
 
 
 def test_t2i_style_config_single_token_context_cfg_plms():
