@@ -18,6 +18,10 @@ from .engine import rup
 
 import os
 CHAIN_FF = os.environ.get("FRIDO_CHAIN_FF", "1") != "0"     # FF2 + proj_out of a transformer block as one GEMM (A/B switch)
+# ERROR-BUDGET EXPERIMENTS (tools/x3_single_plane_table.py, profiles/r03_x3_single_plane_table.txt): keep ONE bf16 plane of an operand
+# class inside the bf16x3 mode.  Off by default -- every one of them fails the parity bar.
+X3_SPADE_BF16 = os.environ.get("FRIDO_X3_SPADE_BF16", "0") != "0"       # hoisted SPADE gamma / beta maps stored as bf16
+X3_CROSSKV_HI = os.environ.get("FRIDO_X3_CROSSKV_HI", "0") != "0"       # cached cross-attention K / V^T: residual (lo) planes zeroed
 
 
 class UNetStagePlan:
@@ -71,11 +75,11 @@ class UNetStagePlan:
     def _persistent_act(self, rows, C):
         """Persistent [rows][C] activation in the stream dtype (bf16 in bf16 mode, f32 in bf16x3 mode)."""
         b = self.b
-        dt = torch.bfloat16 if b.stream_bf16 else torch.float32
-        t = torch.empty(rows, C, dtype=dt, device=b.device)
+        as_bf16 = b.stream_bf16 or X3_SPADE_BF16
+        t = torch.empty(rows, C, dtype=torch.bfloat16 if as_bf16 else torch.float32, device=b.device)
         b._persist.append(t)
         w = self._T(t)
-        w.bf16 = b.stream_bf16
+        w.bf16 = as_bf16
         return w
 
     def _pack_x(self, c0, c1):
@@ -125,6 +129,9 @@ class UNetStagePlan:
                 b.linear(ctx_op, None, wop=wkq, bias=False, out=("op", k))
                 wvo, bvo = b.folded_vo_weight(t + ".to_v", t + ".to_out.0")
                 vT = b.v_transposed(ctx_op, a.context_dim, wvo, self.Bx, self.nctx, C)
+                if X3_CROSSKV_HI and b.nsplit == 2:
+                    for o_ in (k, vT):      # zero the residual planes: the cache then carries 8 mantissa bits
+                        prog.emit("FRIDO_OP_FILL", dst=o_.ptr + 2 * o_.lo, n=o_.lo // 2, value=0)
                 self.kv[blk.prefix] = (k, vT, bvo)
         ctx_op.free()
         # ---- SPADE conditioning (spade_norm.py:44-60), timestep-invariant within a stage ----
