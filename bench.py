@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--allow-debug", action="store_true", help="accept FRIDO_DEBUG_SKIP / FRIDO_GEMM_FLAGS (work-skipping timing experiments)")
     ap.add_argument("--retune", action="store_true", help="let this run (re)write the pinned tile cache")
     args = ap.parse_args()
-    debug_env = {k: v for k, v in os.environ.items() if k in ("FRIDO_DEBUG_SKIP", "FRIDO_GEMM_FLAGS") and v not in ("", "0")}
+    debug_env = {k: v for k, v in os.environ.items() if k in ("FRIDO_DEBUG_SKIP", "FRIDO_GEMM_FLAGS", "FRIDO_X3_SPADE_BF16", "FRIDO_X3_CROSSKV_HI") and v not in ("", "0")}
     if debug_env and not args.allow_debug:
         sys.exit(f"bench.py: {debug_env} drop work from the timed region; pass --allow-debug for a timing experiment "
                  "(the line then carries \"debug_work_skipped\": true and is not a benchmark result)")

@@ -242,6 +242,75 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         }
         return;
     }
+    // bf16x3 stream fast path (r03): f32 rows in, hi / lo operand planes out.  8 channels per lane -- two 16-byte loads per
+    // tensor and ONE 16-byte store per plane (the generic loop below moves 4 channels: 8-byte stores) -- and two independent
+    // vectors in flight per lane.  Same per-element arithmetic as the generic loop.
+    if (!d.x_bf16 && d.nsplit == 2 && d.out_op && !d.out_f32 && (!d.gamma || !d.gb_bf16) && ((d.C1 | d.C2) & 7) == 0) {
+        const unsigned C8 = (unsigned)C >> 3;
+        const unsigned total8 = (unsigned)d.HW * C8;
+        const float* xf1 = reinterpret_cast<const float*>(d.x1);
+        const float* xf2 = reinterpret_cast<const float*>(d.x2);
+        const float* gf = reinterpret_cast<const float*>(d.gamma);
+        const float* bf = reinterpret_cast<const float*>(d.beta);
+        struct Vec { float4 x0, x1, g0, g1, b0, b1; int64_t o; int c; };
+        auto one = [&](unsigned i, Vec& v) {
+            const unsigned p = i / C8;
+            v.c = (int)(i - p * C8) * 8;
+            const int64_t pix = (int64_t)b * d.HW + p;
+            v.o = pix * C + v.c;
+            const float* src = v.c < d.C1 ? xf1 + pix * d.C1 + v.c : xf2 + pix * d.C2 + (v.c - d.C1);
+            v.x0 = *reinterpret_cast<const float4*>(src);
+            v.x1 = *reinterpret_cast<const float4*>(src + 4);
+            if (d.gamma) {
+                v.g0 = *reinterpret_cast<const float4*>(gf + v.o);
+                v.g1 = *reinterpret_cast<const float4*>(gf + v.o + 4);
+                v.b0 = *reinterpret_cast<const float4*>(bf + v.o);
+                v.b1 = *reinterpret_cast<const float4*>(bf + v.o + 4);
+            }
+        };
+        auto fin = [&](const Vec& v) {
+            const float xin[8] = {v.x0.x, v.x0.y, v.x0.z, v.x0.w, v.x1.x, v.x1.y, v.x1.z, v.x1.w};
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = fmaf(xin[e], s_sc[v.c + e], s_sh[v.c + e]);
+            if (d.gamma) {
+                const float ga[8] = {v.g0.x, v.g0.y, v.g0.z, v.g0.w, v.g1.x, v.g1.y, v.g1.z, v.g1.w};
+                const float be[8] = {v.b0.x, v.b0.y, v.b0.z, v.b0.w, v.b1.x, v.b1.y, v.b1.z, v.b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = fmaf(y[e], 1.f + ga[e], be[e]);
+            }
+            if (d.act == FRIDO_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+            }
+            uint32_t h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+            *reinterpret_cast<uint4*>(d.out_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            *reinterpret_cast<uint4*>(d.out_op + d.out_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            if (d.raw_op) {                 // concatenated raw operand for the 1x1 skip conv
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split_bf16(xin[e], h[e], l[e]);
+                *reinterpret_cast<uint4*>(d.raw_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                *reinterpret_cast<uint4*>(d.raw_op + d.raw_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            }
+        };
+        const unsigned stride = gridDim.x * 256u;
+        unsigned i = blockIdx.x * 256u + t;
+        for (; i + stride < total8; i += 2 * stride) {
+            Vec v0, v1;
+            one(i, v0);
+            one(i + stride, v1);
+            fin(v0);
+            fin(v1);
+        }
+        if (i < total8) {
+            Vec v0;
+            one(i, v0);
+            fin(v0);
+        }
+        return;
+    }
     const unsigned total = (unsigned)d.HW * (unsigned)C4;      // < 2^31 on every shape of this path
     for (unsigned i = blockIdx.x * 256u + t; i < total; i += gridDim.x * 256u) {
         const unsigned p = i / (unsigned)C4;
