@@ -143,6 +143,8 @@ __device__ __forceinline__ int chan_of_pos(int p) {      // LDS row (position in
     return (p & ~31) | ((p & 12) << 1) | ((p & 16) >> 2) | (p & 3);
 }
 
+constexpr int SK_HDR = 16384;           // split-K workspace header: arrival tickets (uint32 each), then the partial sums
+
 template <int OFF>
 __device__ __forceinline__ void lds_write128(unsigned addr, f32x4 v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
@@ -150,7 +152,9 @@ __device__ __forceinline__ void lds_write128(unsigned addr, f32x4 v) {
 
 template <int BM, int BN, int NS, int WM, bool RSTAGE>
 __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[BM / WM / 16][BN / 2 / 16], unsigned char* smem,
-                                              int m0, int n0, int wave, int lane, int zo, int zi, int kz) {
+                                              int m0, int n0, int wave, int lane, int zo, int zi, int kz, bool reduced = false) {
+    // `reduced`: split-K launch whose slices were already added up in this workgroup's accumulators (FridoGemm.sk_mode 1): the
+    // full epilogue runs as if there were no split
     constexpr int WN = 2, TM = BM / WM / 16, TN = BN / WN / 16, TJ = TN / 2;
     static_assert(TN % 2 == 0, "n-tile pairs");
     const int wm = wave >> 1, wn = wave & 1;
@@ -171,12 +175,13 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
     if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
     const int nbase = n0 + wn * WC;
     // vector paths (8 columns per lane: 16-byte bf16 / 2 x 16-byte f32 accesses) need 8-element aligned rows and planes
-    const bool vec_ok = gridDim.z > 1 ? (d.N & 3) == 0
+    const bool partial = gridDim.z > 1 && !reduced;
+    const bool vec_ok = partial ? (d.N & 3) == 0
                                       : ((d.ldo | d.ldr | d.ldoo | d.ldv | d.N | d.of_bs | d.of_bs2 | d.oo_bs | d.oo_bs2 | d.res_bs | d.oo_lo) & 7) == 0;
     const int64_t of_base = (int64_t)zo * d.of_bs + (int64_t)zi * d.of_bs2;
     const int64_t oo_base = (int64_t)zo * d.oo_bs + (int64_t)zi * d.oo_bs2;
     const int64_t rs_base = (int64_t)zo * d.res_bs;
-    float* wsp = gridDim.z > 1 ? d.ws + (int64_t)kz * d.M * d.N : nullptr;
+    float* wsp = partial ? d.ws + SK_HDR + (int64_t)kz * d.M * d.N : nullptr;
     // 2x2 phase convolution of an upsample: GEMM row (img, y, x) -> output row (img, 2y + a, 2x + b); Ho, Wo powers of two
     const int up2 = d.up2_phase == 5 ? zo + 1 : d.up2_phase;
     const int lw = 31 - __builtin_clz((unsigned)(d.Wo > 0 ? d.Wo : 1)), lhw = lw + 31 - __builtin_clz((unsigned)(d.Ho > 0 ? d.Ho : 1));
@@ -1154,7 +1159,66 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
 
     }
 
-    tile_epilogue<BM, BN, NS, WM, G::RSTAGE>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz);
+    // ---- in-kernel split-K reduction (FridoGemm.sk_mode 1, r03 A/B): every slice parks its accumulators in the workspace,
+    //      fragment-major (16 coalesced bytes per lane and fragment); the LAST workgroup of the tile to arrive adds all slices in
+    //      slice order -- the sum does not depend on who is last -- and runs the normal epilogue.  Nobody waits for anybody.
+    bool reduced = false;
+    if (gridDim.z > 1 && d.sk_mode == 1) {
+        constexpr int NT = G::NT, SLAB = BM * BN;
+        const int S = (int)gridDim.z;
+        float* part = d.ws + SK_HDR + (int64_t)bid * S * SLAB;
+        {
+            float* mine = part + (int64_t)kz * SLAB + t * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(mine + (i * TN + j) * NT * 4) = acc[i][j];
+        }
+        // hand-off recipe of cdna_hip_programming.md section 6 G16 (counter form): every wave drains its slab stores, ONE lane
+        // releases at agent scope (L2 write-back: the slices of a tile sit on different XCDs) and takes the ticket; the last
+        // arriver's lane 0 acquires, then every wave reads the slabs with plain loads.  (__threadfence() in every lane -- the
+        // first form tried -- made every workgroup pay ~0.25 us of serialized L2 maintenance: 2-6x slower launches.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // (also: every wave is done with the ring)
+        volatile int* flag = reinterpret_cast<volatile int*>(smem);
+        if (t == 0) {
+            unsigned* tickets = reinterpret_cast<unsigned*>(d.ws);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned prev = __hip_atomic_fetch_add(tickets + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == (unsigned)(S - 1);
+            if (last) {
+                __hip_atomic_store(tickets + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // header stays zero for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        const int last = *flag;
+        __syncthreads();                        // the flag has been read by everyone before the epilogue reuses the ring
+        if (!last) return;
+        const float* src = part + t * 4;
+        static_for<0, TM * TN / 2>([&](auto fc) {
+            constexpr int f0 = 2 * decltype(fc)::value, f1 = f0 + 1;
+            f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            for (int z0 = 0; z0 < S; z0 += 8) {
+                f32x4 p0[8], p1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (z0 + u < S) {
+                        p0[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(z0 + u) * SLAB + f0 * NT * 4);
+                        p1[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(z0 + u) * SLAB + f1 * NT * 4);
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (z0 + u < S) { s0 += p0[u]; s1 += p1[u]; }
+            }
+            acc[f0 / TN][f0 % TN] = s0;
+            acc[f1 / TN][f1 % TN] = s1;
+        });
+        reduced = true;
+    }
+    tile_epilogue<BM, BN, NS, WM, G::RSTAGE>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz, reduced);
 }
 
 // =====================================================================================================================
@@ -1655,13 +1719,26 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) 
     const int64_t plane = (int64_t)d.M * d.N;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const int m = (int)(i / (unsigned)n8), n = (int)(i - (unsigned)m * (unsigned)n8) * 8;
-        const float* w = d.ws + (int64_t)m * d.N + n;
+        const float* w = d.ws + SK_HDR + (int64_t)m * d.N + n;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        for (int z = 0; z < d.splitk; ++z) {
-            const float4 a = *reinterpret_cast<const float4*>(w + z * plane), b = *reinterpret_cast<const float4*>(w + z * plane + 4);
-            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        // up to 8 slices' loads in flight per lane (a rolled loop kept ONE pair in flight: S dependent round trips to partials that
+        // other XCDs wrote, ~1 us each); the additions keep the slice order, so the sums are bit-identical to the rolled form
+        for (int z0 = 0; z0 < d.splitk; z0 += 8) {
+            float4 a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (z0 + u < d.splitk) {
+                    a[u] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane);
+                    b[u] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane + 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (z0 + u < d.splitk) {
+                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                }
         }
         float add[8];
 #pragma unroll
@@ -1737,7 +1814,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / d.N), n = (int)(i - (int64_t)m * d.N);
         float a = 0.f;
-        for (int z = 0; z < d.splitk; ++z) a += d.ws[(int64_t)z * total + i];
+        for (int z = 0; z < d.splitk; ++z) a += d.ws[SK_HDR + (int64_t)z * total + i];
         float v = a * d.alpha + (d.bias ? d.bias[n] : 0.f);
         if (d.row_bias) v += d.row_bias[m];
         if (d.rowvec) v += d.rowvec[(int64_t)(m / d.rows_per_vec + vstep) * d.ldv + n];
@@ -1775,9 +1852,20 @@ int launch(const FridoGemm& d, hipStream_t s) {
     constexpr int smem = Geo<BM, BN, NS, BK, W8>::SMEM;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const int sk = d.splitk > 1 ? d.splitk : 1;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK, W8>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK, W8>::NT), smem, s, d);
+    if (sk > 1 && d.sk_mode == 1 && tiles > SK_HDR) {
+        frido_set_error("igemm: sk_mode 1 has %d ticket slots, the launch has %d output tiles", SK_HDR, tiles);
+        return FRIDO_EINVAL;
+    }
+    if (sk > 1 && d.sk_mode == 1) {                         // the last workgroup of each tile reduces: no second launch
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK, W8>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK, W8>::NT), smem, s, d);
+        return frido_check_launch("igemm");
+    }
+    FridoGemm dd = d;
+    dd.sk_mode = 0;
+    if (sk > 1) dd.gn_part = nullptr;                       // (validated: only sk_mode 1 may carry gn_part under split-K)
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK, W8>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK, W8>::NT), smem, s, dd);
     if (sk > 1) {
-        launch_splitk_reduce(d, s);
+        launch_splitk_reduce(dd, s);
     }
     return frido_check_launch("igemm");
 }
@@ -1907,7 +1995,10 @@ static int ensure_device_attrs() {
 
 extern "C" int64_t frido_gemm_workspace_bytes(const FridoGemm* d) {
     if (!d || d->splitk <= 1) return 0;
-    return (int64_t)d->splitk * d->M * d->N * (int64_t)sizeof(float);
+    // sk_mode 1 stores whole tiles: M, N padded to the largest tile edge of the family is an upper bound for every tile choice
+    const int64_t Mp = d->sk_mode == 1 ? ((int64_t)d->M + 255) / 256 * 256 + 0 : d->M;
+    const int64_t Np = d->sk_mode == 1 ? ((int64_t)d->N + 383) / 384 * 384 : d->N;
+    return (int64_t)SK_HDR * 4 + (int64_t)d->splitk * Mp * Np * (int64_t)sizeof(float);
 }
 
 extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
@@ -1944,7 +2035,7 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     }
     if (d.gn_part) {
         FRIDO_REQUIRE(d.nsplit == 2 && d.out_f32 && !d.out_bf16 && !d.out_op && d.act == FRIDO_ACT_NONE && !d.row_bias && !d.geglu &&
-                          !d.up2_phase && d.splitk <= 1 && d.batch == 1 && !(d.flags & 18) && (d.N & 7) == 0 && (d.M & 31) == 0 &&
+                          !d.up2_phase && (d.splitk <= 1 || d.sk_mode == 1) && d.batch == 1 && !(d.flags & 18) && (d.N & 7) == 0 && (d.M & 31) == 0 &&
                           ((d.ldo | d.ldr | d.ldv | d.of_bs | d.res_bs) & 7) == 0 && !(d.residual && d.res_bf16) &&
                           (!d.rowvec || d.rows_per_vec >= (1 << 29)),
                       "gn_part needs the store-from-registers f32 epilogue (see frido_hip.h)");
@@ -1952,6 +2043,7 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     if (d.splitk > 1) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
         FRIDO_REQUIRE(d.splitk <= ((d.K + d.K2) >> 6), "more K slices than k-tiles");
+        FRIDO_REQUIRE(d.sk_mode == 0 || d.sk_mode == 1, "sk_mode must be 0 or 1");
     }
     if (const int arc = ensure_device_attrs()) return arc;
     const int tile = d.tile ? d.tile : pick_tile(d);

@@ -258,10 +258,11 @@ class Prog:
             st = self.ops[-1][1]
             st.tile, st.splitk = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
             if st.splitk > 1:
-                st.gn_part = None       # the split-K reduction kernel does not produce them (the consumer falls back to gn_stats)
+                st.sk_mode = tune.SK_MODE
+                if not st.sk_mode:
+                    st.gn_part = None   # the split-K reduction kernel does not produce them (the consumer falls back to gn_stats)
                 # ops of the executor's side stream run CONCURRENTLY with main-stream ops: they get their own workspace
-                st.ws = tune.workspace(self.device, _lib.lib().frido_gemm_workspace_bytes(C.addressof(st)),
-                                       self.ws_tag + (":s1" if self._sid else ""))
+                st.ws = tune.workspace_for(st, self.device, self.ws_tag + (":s1" if self._sid else ""))
         self.flops += 2 * M * N * (K + K2) * batch * (3 if self.nsplit == 2 else 1)
 
     # ---- execution ---------------------------------------------------------------------------

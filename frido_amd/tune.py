@@ -24,6 +24,8 @@ BIG_SPLITK = os.environ.get("FRIDO_TUNE_BIG_SPLITK", "1") != "0"      # also try
 # 256 MB MALL per forward) while its activations were just written; timed back to back on one buffer the weights sit in L2 /
 # MALL instead.  With this on, consecutive repetitions read different copies of the weight operand out of a >= 320 MB ring.
 COLD_B = os.environ.get("FRIDO_TUNE_COLD_B", "0") != "0"
+# who adds split-K partial sums (FridoGemm.sk_mode): 0 = the splitk_reduce launch, 1 = the last workgroup of each tile, in-kernel
+SK_MODE = int(os.environ.get("FRIDO_SPLITK_MODE", "0"))
 CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
 _dirty = False
 
@@ -31,10 +33,11 @@ _dirty = False
 def _lib_tag():
     if os.environ.get("FRIDO_TUNE_TAG"):      # A/B of two library builds with the SAME pinned tiles (tools/ab_lib.sh)
         return os.environ["FRIDO_TUNE_TAG"]
+    mode = f"+sk{SK_MODE}" if SK_MODE else ""       # tiles tuned under another split-K reduction are not comparable
     try:
         import hashlib
         with open(_lib.LIB_PATH, "rb") as f:      # content hash: two builds of equal size must not share pinned tiles
-            return hashlib.sha256(f.read()).hexdigest()[:16]
+            return hashlib.sha256(f.read()).hexdigest()[:16] + mode
     except OSError:
         return "?"
 
@@ -81,6 +84,11 @@ def _buf(name, nbytes, device):
 _ws = {}
 
 
+def workspace_for(st, device, tag=""):
+    """Workspace of a filled FridoGemm descriptor with splitk > 1 (sized by the library: ticket header + partial sums)."""
+    return workspace(device, _lib.lib().frido_gemm_workspace_bytes(C.addressof(st)), tag)
+
+
 def workspace(device, nbytes, tag=""):
     """Split-K workspace: one per (device, tag).  Ops of all programs of one builder run in stream order, so they share one
     buffer; builders whose programs run CONCURRENTLY on different streams pass their own tag."""
@@ -88,7 +96,7 @@ def workspace(device, nbytes, tag=""):
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         old = t
-        t = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=device)
+        t = torch.zeros(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=device)      # zero: the ticket header (frido_hip.h)
         _ws[key] = t
         if old is not None:
             _ws.setdefault(key + ":old", []).append(old)      # descriptors emitted earlier still point at it
@@ -155,7 +163,8 @@ def best_tile(st, device, stream):
         splits = [1]          # the split-K reduction writes rows in order; phase convs interleave them
     for sk in splits:
         t.splitk = sk
-        t.ws = workspace(device, sk * st.M * st.N * 4) if sk > 1 else None
+        t.sk_mode = SK_MODE
+        t.ws = workspace_for(t, device) if sk > 1 else None
         # BK = 64 halves the barrier count but costs a ring stage of occupancy: it only wins on small-M shapes
         k64 = (st.nsplit == 1 and st.K % 64 == 0 and st.K2 % 64 == 0 and (not st.conv or st.Cin % 64 == 0) and (st.K // 64) >= sk
                and (st.M * st.batch <= 4096 or K64_ALL))

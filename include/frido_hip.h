@@ -86,15 +86,21 @@ typedef struct FridoGemm {
     int32_t batch_inner;        /* > 1: blockIdx.y = zo * batch_inner + zi (e.g. batch x heads); the *_bs strides apply
                                    to zo and the *_bs2 strides to zi */
     int64_t a_bs2, b_bs2, of_bs2, oo_bs2;
-    int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to `ws` [splitk][M][N] f32 and a
-                                   second kernel reduces them in a fixed order and applies the epilogue (batch == 1) */
-    float* ws;
+    int32_t splitk;             /* > 1: K is split over gridDim.z; partial sums go to the workspace `ws` and are added in slice
+                                   order 0 .. splitk-1 (bit-identical run to run), batch == 1.  Size: frido_gemm_workspace_bytes. */
+    float* ws;                  /* [64 KiB of arrival tickets -- ZERO before the first launch that uses the buffer, left zero by
+                                   every launch][partial sums] */
+    int32_t sk_mode;            /* who adds the partial sums: 0 = a second kernel (splitk_reduce: [splitk][M][N] partials);
+                                   1 = the LAST workgroup of each output tile to arrive (ticket per tile, agent-scope release /
+                                   acquire around it; partials stored fragment-major per tile), which then runs the GEMM's own
+                                   epilogue -- no second launch, and gn_part stays available.  Ring kernels only (the bf16
+                                   patch-staged 3x3 kernel always uses 0); at most 16384 output tiles. */
     float* gn_part;             /* optional (bf16x3 f32-stream outputs): per-channel partial {sum, sum of squares} of the STORED values
                                    over every 32-row block, gn_part[((m / 32) * N + n) * 2 + {0, 1}], written by the store-from-
                                    registers epilogue; frido_gn_stats (p1 / p2) turns them into GroupNorm statistics without
                                    re-reading the tensor (pyunet.py:262-300: every GroupNorm input is a conv / linear output).
-                                   Needs: nsplit 2, f32 output only, no activation / row bias / GEGLU / split-K / batching /
-                                   upsample phases, N % 8 == 0, M % 32 == 0 (rejected otherwise) */
+                                   Needs: nsplit 2, f32 output only, no activation / row bias / GEGLU / two-kernel split-K /
+                                   batching / upsample phases, N % 8 == 0, M % 32 == 0 (rejected otherwise) */
     int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 (BK 32);
                                    7 = 256x128 (8 waves), 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64), 17 = 256x128 with BK 64;
@@ -320,9 +326,10 @@ typedef struct FridoOp {
 
 /* ---- single-op launchers ---- */
 int frido_gemm(const FridoGemm* d, frido_stream_t s);
-/* Bytes of the split-K workspace `ws` a descriptor needs (0 when splitk <= 1): splitk * M * N floats.  The caller owns the
- * buffer (one per stream is enough: launches on a stream are ordered); a host that is not the bundled Python runtime sizes
- * it with this call instead of reading frido_amd/tune.py. */
+/* Bytes of the split-K workspace `ws` a descriptor needs (0 when splitk <= 1): the 64-KiB ticket header + splitk * M' * N'
+ * floats (M', N' padded to whole tiles for sk_mode 1).  The caller owns the buffer and ZEROES it once when it allocates it
+ * (one per stream is enough: launches on a stream are ordered); a host that is not the bundled Python runtime sizes it with
+ * this call instead of reading frido_amd/tune.py. */
 int64_t frido_gemm_workspace_bytes(const FridoGemm* d);
 int frido_gn_stats(const FridoGnStats* d, frido_stream_t s);
 int frido_gn_apply(const FridoGnApply* d, frido_stream_t s);

@@ -63,9 +63,11 @@ def main():
         st.act = 100 - int(os.environ["NOEPI"])
     sk = int(os.environ.get("SPLITK", "1"))
     if sk > 1:
-        st.gn_part = None          # (split-K launches do not produce the fused GroupNorm partial sums)
         st.splitk = sk
-        st.ws = tune.workspace(dev, sk * st.M * st.N * 4)
+        st.sk_mode = int(os.environ.get("SKMODE", "0"))      # 1: in-kernel reduction by the last workgroup of each tile
+        if not st.sk_mode:
+            st.gn_part = None      # (the two-kernel reduction does not produce the fused GroupNorm partial sums)
+        st.ws = tune.workspace_for(st, dev)
     for tile in tiles:
         st.tile = tile
         arr = _lib.pack_ops([(kind, st)] * reps)
