@@ -16,6 +16,7 @@ UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample con
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
 GN_EPI_STATS = os.environ.get("FRIDO_GN_EPI_STATS", "1") != "0"   # GroupNorm partial sums from the producing GEMM's epilogue (bf16x3 f32 stream)
+LN_IN_ATTN = os.environ.get("FRIDO_LN_IN_ATTN", "1") != "0"       # norm2 / norm3 of a transformer block from the attention kernel's epilogue (A/B switch)
 ATTN_FLASH = os.environ.get("FRIDO_ATTN_FLASH", "1") != "0"       # flash-style kernel for long key sequences (flash.hip)
 # below this many keys the score matrix is small and the batched GEMM -> softmax -> GEMM chain fills the chip better than
 # one workgroup per 64 queries (measured at B = 16: 256 keys x d = 576: 37 us vs 49 us; 1024 keys x d = 384: 102 vs 82 us)
@@ -451,10 +452,13 @@ class Builder:
 
     # ---- attention (single head, unfused: QK^T -> softmax -> PV on the MFMA GEMM) -----------------
     def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0, bias_ptr=None, residual=None, stream=False,
-                  also_op=False):
+                  also_op=False, ln=None):
         """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
         [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158).
-        stream=True (the out projection is folded into vT): returns the residual-stream activation O + bias + residual."""
+        stream=True (the out projection is folded into vT): returns the residual-stream activation O + bias + residual.
+        ln=(weight name, eps) with stream=True in bf16x3 mode: where the kernel's workgroups own whole rows (flash kernel with
+        d = 256 / 384, short-key kernel with >= 256 workgroups) the LayerNorm of the result comes back as the operand `res.ln_copy`
+        from the same launch; otherwise the attribute is absent and the caller runs layernorm()."""
         Np = rup(Nk, 32)
         aligned = ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0
         small = Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and aligned
@@ -470,6 +474,12 @@ class Builder:
             if stream:
                 res = self.f32(B * Nq, d)
                 assert residual is None or getattr(residual, "bf16", False) == res.bf16
+                if ln is not None and LN_IN_ATTN and not res.bf16 and self.nsplit == 2 and (
+                        (flash and d in (256, 384)) or (small and B * (Nq // 16) >= 256)):
+                    n = self.op(B * Nq, d)
+                    kw.update(ln_op=n.ptr, ln_lo=n.lo, ld_ln=d, ln_w=self.bias(ln[0] + ".weight"), ln_b=self.bias(ln[0] + ".bias"),
+                              ln_eps=ln[1])
+                    res.ln_copy = n
                 if also_op and small and not res.bf16:
                     # the short-key kernel also leaves the stream values as an operand (hi / lo planes): returns (stream, operand)
                     o = self.op(B * Nq, d)

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     float* so = s_part + wave * 16 * SO_LD;         // this wave's transpose slab (the partial scores are dead by now)
     constexpr int CPL = G * 4;                      // columns per lane on the read-back: 16 rows x 4 lanes
     const int orow = lane >> 2, oc = (lane & 3) * CPL;
+    float ln_s = 0.f, ln_q = 0.f;                  // LayerNorm of the stream rows (ln_op): this lane's share of its row's sum / sum of squares
     for (int tb = t0; tb < t1; tb += G) {
         const int ng = t1 - tb < G ? t1 - tb : G;
         f32x4 acc[G];
@@ -205,6 +206,8 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo + i * 4) = v;
                     }
                     keep[i * 4] = v.x; keep[i * 4 + 1] = v.y; keep[i * 4 + 2] = v.z; keep[i * 4 + 3] = v.w;
+                    ln_s += (v.x + v.y) + (v.z + v.w);
+                    ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
                 if (d.out_op) {                 // operand copy of the stream values (A2 of the chained FF2 + proj_out GEMM)
                     frido_bf16* dst = d.out_op + (int64_t)(row0 + orow) * d.ldo + col;
@@ -233,6 +236,47 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                         *reinterpret_cast<uint4*>(dst + d.out_lo + i * 8) =
                             make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
                 }
+            }
+        }
+    }
+    // ---- (r03) LayerNorm of the 16 stream rows this workgroup just wrote, as an operand: norm2 / norm3 of the transformer block
+    //      (attention.py:225-226) without their own launch.  gridDim.y == 1 (validated): the workgroup owns the whole rows.
+    if (d.ln_op) {
+        ln_s += __shfl_xor(ln_s, 1, 64); ln_s += __shfl_xor(ln_s, 2, 64);      // the four lanes of a row
+        ln_q += __shfl_xor(ln_q, 1, 64); ln_q += __shfl_xor(ln_q, 2, 64);
+        __syncthreads();                            // every wave is done with its transpose slab: s_part is free
+        if ((lane & 3) == 0) {
+            s_part[(wave * 16 + orow) * 2] = ln_s;
+            s_part[(wave * 16 + orow) * 2 + 1] = ln_q;
+        }
+        __syncthreads();
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { S += s_part[(w * 16 + orow) * 2]; Q += s_part[(w * 16 + orow) * 2 + 1]; }      // fixed order
+        const float mean = S / d.dv;
+        const float var = fmaxf(Q / d.dv - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + d.ln_eps);
+        // second pass over this lane's OWN stores (same thread, same addresses: program order)
+        const float* xr = reinterpret_cast<const float*>(d.out_act) + (int64_t)(row0 + orow) * d.ld_act;
+        frido_bf16* dst = d.ln_op + (int64_t)(row0 + orow) * d.ld_ln;
+        for (int tb = t0; tb < t1; tb += G) {
+            const int ng = t1 - tb < G ? t1 - tb : G;
+            if (oc >= ng * 16) continue;
+            const int col = tb * 16 + oc;
+#pragma unroll
+            for (int i = 0; i < CPL / 8; ++i) {
+                const int c = col + i * 8;
+                const float4 x0 = *reinterpret_cast<const float4*>(xr + c), x1 = *reinterpret_cast<const float4*>(xr + c + 4);
+                const float4 w0 = *reinterpret_cast<const float4*>(d.ln_w + c), w1 = *reinterpret_cast<const float4*>(d.ln_w + c + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(d.ln_b + c), b1 = *reinterpret_cast<const float4*>(d.ln_b + c + 4);
+                const float y[8] = {(x0.x - mean) * rstd * w0.x + b0.x, (x0.y - mean) * rstd * w0.y + b0.y, (x0.z - mean) * rstd * w0.z + b0.z,
+                                    (x0.w - mean) * rstd * w0.w + b0.w, (x1.x - mean) * rstd * w1.x + b1.x, (x1.y - mean) * rstd * w1.y + b1.y,
+                                    (x1.z - mean) * rstd * w1.z + b1.z, (x1.w - mean) * rstd * w1.w + b1.w};
+                uint32_t h[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+                *reinterpret_cast<uint4*>(dst + c) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                *reinterpret_cast<uint4*>(dst + d.ln_lo + c) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
         }
     }
@@ -266,6 +310,9 @@ extern "C" int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s) {
                       (d->vt_lo & 7) == 0 && (d->out_lo & 7) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
                   "strides and plane offsets must keep 16-byte alignment");
     FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
+    FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && d->B * (d->Nq / 16) >= 256 && d->ln_w && d->ln_b &&
+                                (d->ld_ln & 7) == 0 && (d->ln_lo & 7) == 0),
+                  "ln_op: bf16x3 f32-stream output, B * Nq / 16 >= 256 (one workgroup per 16 rows owns them whole), weight and bias given");
     if (d->nsplit == 2) launch_attn<2>(*d, (hipStream_t)s);
     else launch_attn<1>(*d, (hipStream_t)s);
     return frido_check_launch("attn_small");

@@ -358,6 +358,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
     // ---- epilogue: lane holds O^T[c = 16 ct + 4 g + e][q = r]: four consecutive channels of its query per fragment ----
     if (!q_ok) return;
     const float inv = 1.0f / l_run;
+    // (validated: f32 stream output, this workgroup owns whole rows.  Instantiated for the U-Net's head widths only: in the d = 128
+    //  kernel the extra live range pushed hipcc into scratch)
+    const bool ln = OS == 1 && NS == 2 && D >= 256 && d.ln_op != nullptr;
+    float lsum = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int col = c_base + c * 16 + g * 4;
@@ -377,9 +381,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
                     make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
             else
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo) = v;
+            if (ln) {                                    // keep the stored row: its LayerNorm follows
+                o[c] = f32x4{v.x, v.y, v.z, v.w};
+                lsum += (v.x + v.y) + (v.z + v.w);
+            }
         } else {
             const float vv[4] = {v.x, v.y, v.z, v.w};
             store_op4(d.out_op, d.out_lo, NS, grow * d.ldo + col, vv);
+        }
+    }
+    if (ln) {
+        // LayerNorm of the stream row (r03: norm2 of the transformer block, attention.py:225): the four lanes r, r + 16, r + 32,
+        // r + 48 hold the D channels of query r, so mean / variance are two in-wave reductions; same two-pass arithmetic as
+        // layernorm_kernel
+        const float mean = xor_sum(lsum) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float a0 = o[c][0] - mean, a1 = o[c][1] - mean, a2 = o[c][2] - mean, a3 = o[c][3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float rstd = 1.0f / sqrtf(xor_sum(q) * (1.0f / D) + d.ln_eps);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = c * 16 + g * 4;
+            const float4 w = *reinterpret_cast<const float4*>(d.ln_w + col), bb = *reinterpret_cast<const float4*>(d.ln_b + col);
+            const float y[4] = {(o[c][0] - mean) * rstd * w.x + bb.x, (o[c][1] - mean) * rstd * w.y + bb.y,
+                                (o[c][2] - mean) * rstd * w.z + bb.z, (o[c][3] - mean) * rstd * w.w + bb.w};
+            store_op4(d.ln_op, d.ln_lo, NS, grow * d.ld_ln + col, y);
         }
     }
 }
@@ -430,6 +459,9 @@ extern "C" int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s) {
                       (d->vt_lo & 7) == 0 && (d->out_lo & 3) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
                   "strides and plane offsets must keep 16-byte alignment");
     FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
+    FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && (d->d == 256 || d->d == 384) && d->ln_w && d->ln_b && (d->ld_ln & 3) == 0 &&
+                                (d->ln_lo & 3) == 0),
+                  "ln_op: bf16x3 f32-stream output with d = 256 or 384 (the workgroup owns whole rows), weight and bias given");
     hipStream_t st = (hipStream_t)s;
     switch (d->d) {
         case 128: return flash_dispatch<128>(*d, st);

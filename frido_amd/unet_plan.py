@@ -249,19 +249,24 @@ class UNetStagePlan:
             b.v_transposed(n1, C, wvo, Bx, HW, C, out=vT)
         qp = b.linear(n1, None, wop=wq, bias=False, out="op")
         b.prog.sync(1, 0)
-        h2 = b.attention(qp, C, n1, C, vT, Bx, HW, HW, C, bias_ptr=bvo, residual=hcur, stream=True)
+        h2 = b.attention(qp, C, n1, C, vT, Bx, HW, HW, C, bias_ptr=bvo, residual=hcur, stream=True, ln=(t + ".norm2", 1e-5))
         qp.free()
         n1.free()
         hcur.free()
         # --- cross-attention (K, V^T cached per sample)
-        n2 = b.layernorm(h2, t + ".norm2")
+        n2 = getattr(h2, "ln_copy", None)       # (r03) the attention kernel's epilogue may have produced it
+        if n2 is None:
+            n2 = b.layernorm(h2, t + ".norm2")
         kc, vTc, bvo2 = self.kv[pre]            # kc = ctx (W_q^T W_k)^T: the query projection is folded into the cached keys
         chain = CHAIN_FF and C % 64 == 0       # proj_out(h3 + ff2(gg)) + x in ONE GEMM (needs h3 as an operand along K)
-        h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True, also_op=chain)
+        h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True, also_op=chain,
+                         ln=(t + ".norm3", 1e-5))
         n2.free()
         h2.free()
         # --- GEGLU feed-forward (attention.py:37-64)
-        n3 = b.layernorm(h3, t + ".norm3")
+        n3 = getattr(h3, "ln_copy", None)
+        if n3 is None:
+            n3 = b.layernorm(h3, t + ".norm3")
         gg = b.linear_geglu(n3, t + ".ff.net.0.proj")
         n3.free()
         h3op = h3 if b.stream_bf16 else getattr(h3, "op_copy", None)     # bf16 stream: the activation is its own operand

@@ -180,6 +180,12 @@ typedef struct FridoAttnSmall {
     frido_bf16* out_op; int64_t out_lo; int32_t ldo;
     int32_t B, Nq, Nk, d, dv, nsplit; float alpha;
     void* out_act; const void* residual; const float* bias; int32_t ld_act, ldr, act_bf16;
+    /* optional (r03), with the f32 residual-stream output (out_act, act_bf16 = 0) in bf16x3 mode: the LayerNorm of the row just
+       written, (x - mean) * rstd * ln_w + ln_b over the dv channels, as a hi / lo operand [B * Nq][ld_ln] -- the norm2 / norm3 of a
+       transformer block (attention.py:222-227) without a launch of their own and without re-reading the stream from HBM.  The
+       workgroup must own whole rows: frido_attn_flash with d = 256 or 384; frido_attn_small with B * Nq / 16 >= 256 (rejected otherwise). */
+    frido_bf16* ln_op; int64_t ln_lo; int32_t ld_ln;
+    const float* ln_w; const float* ln_b; float ln_eps;
 } FridoAttnSmall;
 
 /* GEGLU gate (attention.py:42-44): x[rows][2H] f32 -> operand [rows][H] = x[:, :H] * gelu_erf(x[:, H:]). */

@@ -465,24 +465,30 @@ def test_attention_core(nsplit, B, Nq, Nk, d):
 
 
 @pytest.mark.parametrize("nsplit", [2, 1])
-@pytest.mark.parametrize("B,Nq,Nk,d", [(2, 64, 26, 384), (2, 64, 64, 960), (2, 256, 256, 64)])
+@pytest.mark.parametrize("B,Nq,Nk,d", [(2, 64, 26, 384), (2, 64, 64, 960), (2, 256, 256, 64), (16, 256, 77, 576), (5, 1024, 26, 384),
+                                       (64, 64, 92, 960)])
 def test_attention_core_stream_output(nsplit, B, Nq, Nk, d):
-    """Residual-stream form used when the output projection is folded into V: softmax(qk^T/sqrt(d)) v + bias + residual."""
+    """Residual-stream form used when the output projection is folded into V: softmax(qk^T/sqrt(d)) v + bias + residual; with
+    >= 256 workgroups the bf16x3 kernel also returns the LayerNorm of its rows (norm2 / norm3, attention.py:225-226)."""
     from frido_amd.engine import pack_matrix
     q, k, v = _t("aq", B, Nq, d), _t("ak", B, Nk, d), _t("av", B, Nk, d)
-    bias, res = _t("ab", d), _t("ar", B * Nq, d)
-    b = _builder(nsplit)
+    bias, res = _t("ab", d), _t("ar", B * Nq, d) + 0.3
+    lw, lb = 1 + 0.2 * _t("lw", d), 0.1 * _t("lb", d)
+    b = _builder(nsplit, {"ln.weight": lw.cuda(), "ln.bias": lb.cuda()})
     qo = pack_matrix(q.reshape(B * Nq, d).cuda(), nsplit)
     ko = pack_matrix(k.reshape(B * Nk, d).cuda(), nsplit)
     vto = pack_matrix(v.transpose(1, 2).reshape(B * d, Nk).cuda(), nsplit)
     bd = bias.cuda()
     r = b.f32(B * Nq, d)
     r.view().copy_(res.cuda())
-    o = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d, bias_ptr=bd.data_ptr(), residual=r, stream=True, also_op=True)
+    o = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d, bias_ptr=bd.data_ptr(), residual=r, stream=True, also_op=True, ln=("ln", 1e-5))
     _run(b)
     rq = r.to_f32().cpu()       # the residual as stored (bf16-rounded in bf16 mode)
     ref = (torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1) @ v).reshape(B * Nq, d) + bias + rq
     assert _relerr(o.to_f32().cpu(), ref) < (5e-5 if nsplit == 2 else 2e-2)
+    assert hasattr(o, "ln_copy") == (nsplit == 2 and Nk <= 128 and B * (Nq // 16) >= 256)
+    if hasattr(o, "ln_copy"):
+        assert _relerr(o.ln_copy.to_f32().cpu(), F.layer_norm(o.to_f32().cpu(), (d,), lw, lb, 1e-5)) < 2e-5
     if nsplit == 2 and Nk <= 128:     # f32 stream: the short-key kernel also left the same values as a hi / lo operand
         assert _relerr(o.op_copy.to_f32().cpu(), o.to_f32().cpu()) < 1e-5
     else:
@@ -512,13 +518,18 @@ def test_attention_flash(nsplit, B, Nq, Nk, d, monkeypatch):
     bd = bias.cuda()
     r = b.f32(B * Nq, d)
     r.view().copy_(res.cuda())
-    o2 = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d, bias_ptr=bd.data_ptr(), residual=r, stream=True)
+    lw, lb = 1 + 0.2 * _t("lw", d), 0.1 * _t("lb", d)
+    b.w.update({"ln.weight": lw.cuda(), "ln.bias": lb.cuda()})
+    o2 = b.attention(qo, d, ko, d, vto, B, Nq, Nk, d, bias_ptr=bd.data_ptr(), residual=r, stream=True, ln=("ln", 1e-5))
     assert sum(kind == _lib.OP_KINDS["FRIDO_OP_ATTN_FLASH"] for kind, _ in b.prog.ops) == 2
     _run(b)
     ref = (torch.softmax(q.double() @ k.double().transpose(1, 2) * d ** -0.5, -1) @ v.double()).float()
     tol = 5e-5 if nsplit == 2 else 2e-2
     assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < tol
     assert _relerr(o2.to_f32().cpu(), ref.reshape(B * Nq, d) + bias + r.to_f32().cpu()) < tol
+    assert hasattr(o2, "ln_copy") == (nsplit == 2 and d in (256, 384))      # the LayerNorm of the stream rows from the same launch
+    if hasattr(o2, "ln_copy"):
+        assert _relerr(o2.ln_copy.to_f32().cpu(), F.layer_norm(o2.to_f32().cpu(), (d,), lw, lb, 1e-5)) < 2e-5
 
 
 def test_attention_flash_online_softmax_rescale_branch(monkeypatch):
