@@ -12,6 +12,7 @@
 //            fragments loaded straight from global memory; groups of 2-4 fragments are transposed through LDS so that the
 //            operand leaves as 16-byte stores.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -155,6 +156,10 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     constexpr int CPL = G * 4;                      // columns per lane on the read-back: 16 rows x 4 lanes
     const int orow = lane >> 2, oc = (lane & 3) * CPL;
     float ln_s = 0.f, ln_q = 0.f;                  // LayerNorm of the stream rows (ln_op): this lane's share of its row's sum / sum of squares
+    // ... and the values themselves, parked in (dynamic) LDS at [row][dv + 4]: every lane reads back only what it wrote itself, so the
+    // second pass needs no barrier -- and no round trip through the stores it has just issued (re-reading out_act cost ~15 us a launch)
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];
+    const int ldrow = d.dv + 4;
     for (int tb = t0; tb < t1; tb += G) {
         const int ng = t1 - tb < G ? t1 - tb : G;
         f32x4 acc[G];
@@ -206,8 +211,11 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo + i * 4) = v;
                     }
                     keep[i * 4] = v.x; keep[i * 4 + 1] = v.y; keep[i * 4 + 2] = v.z; keep[i * 4 + 3] = v.w;
-                    ln_s += (v.x + v.y) + (v.z + v.w);
-                    ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    if (d.ln_op) {
+                        ln_s += (v.x + v.y) + (v.z + v.w);
+                        ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                        *reinterpret_cast<float4*>(s_rows + orow * ldrow + col + i * 4) = v;
+                    }
                 }
                 if (d.out_op) {                 // operand copy of the stream values (A2 of the chained FF2 + proj_out GEMM)
                     frido_bf16* dst = d.out_op + (int64_t)(row0 + orow) * d.ldo + col;
@@ -256,8 +264,8 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
         const float mean = S / d.dv;
         const float var = fmaxf(Q / d.dv - mean * mean, 0.f);
         const float rstd = 1.0f / sqrtf(var + d.ln_eps);
-        // second pass over this lane's OWN stores (same thread, same addresses: program order)
-        const float* xr = reinterpret_cast<const float*>(d.out_act) + (int64_t)(row0 + orow) * d.ld_act;
+        // second pass over the values this lane parked in LDS
+        const float* xr = s_rows + orow * ldrow;
         frido_bf16* dst = d.ln_op + (int64_t)(row0 + orow) * d.ld_ln;
         for (int tb = t0; tb < t1; tb += G) {
             const int ng = t1 - tb < G ? t1 - tb : G;
@@ -282,12 +290,33 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     }
 }
 
+// static + dynamic LDS of the LayerNorm form can pass 64 KiB (eight score fragments, d >= 384): per-device opt-in, set once
+template <int NS, int NW, int NF>
+bool attn_lds_optin() {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel<NS, NW, NF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                16 * (1024 + 4) * (int)sizeof(float)) != hipSuccess)
+            return false;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return true;
+}
+
 template <int NS>
 void launch_attn(const FridoAttnSmall& d, hipStream_t s) {
     const int blocks = d.B * (d.Nq / 16);
     const bool many = blocks >= 512;                    // >= 2 workgroups per CU: the grid hides the latency chain
     const int cs = blocks >= 256 ? 1 : (blocks >= 128 ? 2 : 4);
-#define ATTN_LAUNCH(NW, NF) hipLaunchKernelGGL((attn_small_kernel<NS, NW, NF>), dim3(blocks, cs), dim3(NW * 64), 0, s, d)
+    const size_t dyn = d.ln_op ? (size_t)16 * (d.dv + 4) * sizeof(float) : 0;      // the rows parked for their LayerNorm (<= 62 KiB at dv = 960)
+#define ATTN_LAUNCH(NW, NF)                                                                                               \
+    do {                                                                                                                  \
+        if (dyn && !attn_lds_optin<NS, NW, NF>()) frido_set_error("attn_small: cannot set the dynamic LDS size");         \
+        hipLaunchKernelGGL((attn_small_kernel<NS, NW, NF>), dim3(blocks, cs), dim3(NW * 64), dyn, s, d);                  \
+    } while (0)
     if (d.Nk <= 32) {
         if (many) ATTN_LAUNCH(4, 2); else ATTN_LAUNCH(16, 2);
     } else if (d.Nk <= 64) {
@@ -310,7 +339,7 @@ extern "C" int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s) {
                       (d->vt_lo & 7) == 0 && (d->out_lo & 7) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
                   "strides and plane offsets must keep 16-byte alignment");
     FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
-    FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && d->B * (d->Nq / 16) >= 256 && d->ln_w && d->ln_b &&
+    FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && d->B * (d->Nq / 16) >= 256 && d->dv <= 1024 && d->ln_w && d->ln_b &&
                                 (d->ld_ln & 7) == 0 && (d->ln_lo & 7) == 0),
                   "ln_op: bf16x3 f32-stream output, B * Nq / 16 >= 256 (one workgroup per 16 rows owns them whole), weight and bias given");
     if (d->nsplit == 2) launch_attn<2>(*d, (hipStream_t)s);
