@@ -46,6 +46,23 @@ def table(prog, sp, title, top=None):
         bykind[n][1] += 1
     tot = sum(ms)
     print(f"== {title}: {len(ms)} ops, {tot:.3f} ms (sum of per-op event intervals)")
+    if os.environ.get("ROUNDS"):
+        # GEMM time by the number of workgroup ROUNDS a launch needs (workgroups / resident slots): what a persistent, time-shifted
+        # tile scheduler could overlap only exists in launches that run more than one round
+        dims = {1: (128, 128, 2), 2: (128, 192, 2), 3: (64, 64, 3), 4: (128, 64, 3), 5: (64, 192, 2), 6: (64, 128, 3), 7: (256, 128, 1), 18: (128, 192, 1),
+                0: (64, 64, 3)}
+        buckets = collections.defaultdict(float)
+        gt = 0.0
+        for (kind, st), t in zip(prog.ops, ms):
+            if names[kind] != "GEMM":
+                continue
+            bm, bn, per_cu = dims.get(st.tile % 10 if st.tile not in dims else st.tile, (128, 128, 2))
+            wgs = -(-st.M // bm) * -(-st.N // bn) * max(st.splitk, 1) * st.batch
+            r = wgs / (256.0 * per_cu)
+            buckets["<= 1 round" if r <= 1.0 else ("1 - 2 rounds" if r <= 2.0 else "> 2 rounds")] += t
+            gt += t
+        print("  GEMM-family time by workgroup rounds (workgroups / (256 CUs x resident workgroups per CU)): "
+              + ", ".join(f"{k}: {100 * v / gt:.0f} %" for k, v in sorted(buckets.items())))
     for k, (t, c) in sorted(bykind.items(), key=lambda kv: -kv[1][0]):
         print(f"  {k:12s} {c:4d} launches {t:8.3f} ms {100 * t / tot:5.1f}%")
     agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
