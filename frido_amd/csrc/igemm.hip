@@ -850,7 +850,9 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * ROWB;
     const unsigned b_frag = lds0 + BM * ROWB + (wn * (BN / WN) + frow) * ROWB;
 
-    static_assert(JBR == 0 || (NS == 2 && W8), "uneven weight-chunk dealing: bf16x3 8-wave 128 x 192 tile only");
+    // uneven weight-chunk dealing (12 chunks on 8 waves): the virtual-step loop counts per wave; the plain loop is safe with a 2-slot
+    // ring only (every wait is vmcnt(0))
+    static_assert(JBR == 0 || (NS == 2 && W8) || (NS == 2 && D == 2), "uneven weight-chunk dealing: bf16x3 8-wave 192-column tiles only");
     if constexpr (NS == 1 && BK == 64) {
         // ---- software-pipelined main loop (bf16 mode, BK = 64 tiles).  The fragments of k-step t+1 are read from LDS into a SECOND register set
         //      while the MFMAs of k-step t issue from the first: with one workgroup of 8 waves per CU (or two of 4) the waves
@@ -1921,6 +1923,7 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
     if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
     if constexpr (NS == 2) {
         if (tile == 18) return launch<128, 192, NS, CONV, 32, true>(d, s);     // 128 x 192 on eight waves (bf16x3)
+        if (tile == 19) return launch<256, 192, NS, CONV, 32>(d, s);           // 256 x 192 on eight waves, wave tile 64 x 96 (bf16x3)
     }
     if constexpr (NS == 1) {
         if (tile == 8) return launch<256, 256, NS, CONV, 32>(d, s);
@@ -1964,6 +1967,7 @@ int frido_igemm_init() {
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 2, true, 32>() | set_attr<256, 128, 2, false, 32>();
     rc |= set_attr<128, 192, 2, true, 32, true>() | set_attr<128, 192, 2, false, 32, true>();
+    rc |= set_attr<256, 192, 2, true, 32>() | set_attr<256, 192, 2, false, 32>();
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |
           set_attr<256, 256, 1, false, 32>() | set_attr<256, 128, 1, true, 64>() | set_attr<256, 128, 1, false, 64>();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<192, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,

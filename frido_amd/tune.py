@@ -20,6 +20,7 @@ _scratch = {}
 ENABLED = os.environ.get("FRIDO_TUNE", "1") != "0"
 K64_ALL = os.environ.get("FRIDO_TUNE_K64_ALL", "1") != "0"           # try the BK = 64 tiles on every shape, not only small M
 BIG_SPLITK = os.environ.get("FRIDO_TUNE_BIG_SPLITK", "1") != "0"      # also try the 8-wave 256-row tiles under split-K
+T19 = os.environ.get("FRIDO_TUNE_T19", "1") != "0"                    # bf16x3: the 256 x 192 eight-wave tile is a candidate (A/B switch)
 # Time every candidate with COLD weights: in the sampler a GEMM's weights come from HBM (0.8 GB of them stream through the
 # 256 MB MALL per forward) while its activations were just written; timed back to back on one buffer the weights sit in L2 /
 # MALL instead.  With this on, consecutive repetitions read different copies of the weight operand out of a >= 320 MB ring.
@@ -172,7 +173,7 @@ def best_tile(st, device, stream):
         # tile 9 = patch-staged 3x3 kernel (igemm.hip patch_ok; the library rejects it when it does not apply)
         patch = (st.conv and st.nsplit == 1 and st.batch == 1 and st.kh == 3 and st.stride == 1 and not (st.up_shift or st.dn_shift)
                  and not st.up2_phase and st.M % 128 == 0 and st.M >= 4096 and st.N >= 96 and sk <= (st.Cin + st.K2) // 32)
-        big_tiles = (TILES8W if st.nsplit == 1 else (7, 18)) if big else ()      # bf16x3: 256 x 128 and the 8-wave 128 x 192
+        big_tiles = (TILES8W if st.nsplit == 1 else ((7, 18, 19) if T19 else (7, 18))) if big else ()  # bf16x3: 256 x 128 and the 8-wave 128 x 192 / 256 x 192
         for tile in TILES + (TILES64 if k64 else ()) + big_tiles + ((17,) if big and k64 else ()) + ((9, 10) if patch else ()):
             if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue

@@ -104,7 +104,7 @@ typedef struct FridoGemm {
     int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 (BK 32);
                                    7 = 256x128 (8 waves), 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64), 17 = 256x128 with BK 64;
-                                   18 = 128x192 on eight waves (bf16x3 mode) */
+                                   18 = 128x192 on eight waves, 19 = 256x192 on eight waves (bf16x3 mode) */
     int32_t flags;              /* A/B switches (0 = defaults): bit 0 = do not stage the bf16 residual tile through LDS in the
                                    epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
                                    streamlined epilogues (bit 5 / 6: only the split-K / GEGLU one); TIMING EXPERIMENTS ONLY

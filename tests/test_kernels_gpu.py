@@ -312,7 +312,7 @@ def test_groupnorm_apply(C1, C2, HW, spade, of32):
     assert _relerr(raw.to_f32().cpu(), xc.reshape(B * HW, C)) < 2e-5
 
 
-@pytest.mark.parametrize("C1,C2,H,tile", [(192, 0, 64, 0), (384, 0, 32, 7), (192, 192, 32, 1), (384, 192, 32, 2), (96, 0, 32, 6), (192, 0, 32, 18)])
+@pytest.mark.parametrize("C1,C2,H,tile", [(192, 0, 64, 0), (384, 0, 32, 7), (192, 192, 32, 1), (384, 192, 32, 2), (96, 0, 32, 6), (192, 0, 32, 18), (192, 0, 32, 19)])
 def test_groupnorm_statistics_from_the_conv_epilogue(C1, C2, H, tile, monkeypatch):
     """bf16x3 stream: the convolutions that PRODUCE a GroupNorm's input(s) leave per-channel partial sums of the values they store
     (FridoGemm.gn_part, 32-row blocks); gn_stats sums those instead of re-reading the tensor(s).  Checked against
@@ -577,15 +577,15 @@ def test_fused_geglu_projection(nsplit, M, C):
 
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("out", ["f32", "op"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_gemm_direct_epilogue_every_tile(nsplit, out, tile):
     """The store-from-registers epilogue (transposed accumulators, permuted weight rows): alpha, bias and a stream-dtype residual,
     stream or operand output, on every tile variant; M = 300 and N = 352 (a multiple of 32 and of no tile width) mask rows and
     whole 8-column groups; K = 320 gives the BK = 64 pipelined loop an odd number of k-steps per parity (5 stages)."""
     if tile == 8 and nsplit == 2 or 11 <= tile <= 17 and nsplit == 2:
         pytest.skip("the 256 x 256 and BK = 64 tiles are bf16-mode tiles")
-    if tile == 18 and nsplit == 1:
-        pytest.skip("the 8-wave 128 x 192 tile is a bf16x3 tile")
+    if tile in (18, 19) and nsplit == 1:
+        pytest.skip("the 8-wave 128 x 192 / 256 x 192 tiles are bf16x3 tiles")
     M, N, K = 300, 352, 320
     a, w, bias, res = _t("da", M, K), _t("dw", N, K) / np.sqrt(K), _t("db", N), _t("dr", M, N)
     b = _builder(nsplit, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
@@ -622,7 +622,7 @@ def test_pipelined_loop_short_k(tile, K):
 
 @pytest.mark.parametrize("conv", [False, True])
 @pytest.mark.parametrize("K", [32, 64, 96, 160, 352])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 18])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 18, 19])
 def test_bf16x3_pipelined_loop_short_k(tile, K, conv):
     """The bf16x3 virtual-k-step loop (hi*hi, hi*lo, lo*hi per stage, fragment sets rotating between stages) at 1, 2, 3, 5 and 11
     ring stages: prologue only / no refill / first refill / odd and even stage parities / wrap-around of the 2-4 slot ring; dense
@@ -651,13 +651,13 @@ def test_bf16x3_pipelined_loop_short_k(tile, K, conv):
 
 
 @pytest.mark.parametrize("nsplit", [2, 1])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 11, 12, 14, 17, 18])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 11, 12, 14, 17, 18, 19])
 def test_fused_geglu_projection_every_tile(nsplit, tile):
     """The GEGLU epilogue has two forms: tiles with four-fold n-tile counts (128 / 256 columns) deal the packed rows so that a
     lane owns value and gate of 8 consecutive outputs (direct stores); the others keep the [a | gate] order and go through LDS.
     M is ragged and 2H = 1344 is a multiple of 64 but of no tile width, so every tile masks rows AND columns."""
-    if nsplit == 2 and (11 <= tile <= 17 or tile == 8) or nsplit == 1 and tile == 18:
-        pytest.skip("the 256 x 256 and BK = 64 tiles are bf16-mode tiles; the 8-wave 128 x 192 tile is a bf16x3 tile")
+    if nsplit == 2 and (11 <= tile <= 17 or tile == 8) or nsplit == 1 and tile in (18, 19):
+        pytest.skip("the 256 x 256 and BK = 64 tiles are bf16-mode tiles; the 8-wave 128 x 192 / 256 x 192 tiles are bf16x3 tiles")
     M, C, H = 300, 128, 672
     x, w, bias = _t("gx", M, C), _t("gw", 2 * H, C) / np.sqrt(C), _t("gb", 2 * H)
     b = _builder(nsplit, {"p.weight": w.cuda(), "p.bias": bias.cuda()})
