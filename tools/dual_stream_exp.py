@@ -69,7 +69,10 @@ def main():
             if ref is None:
                 ref = z
             same = float((z - ref).abs().max())
-            print(f"{name:14s} {dt * 1e3:8.1f} ms for {a.batch} latents ({a.batch / dt:.3f} /s, loop only)   max|z - whole| = {same:.3e}", flush=True)
+            rel = float((z - ref).norm() / ref.norm())
+            per = [(float((z[i] - ref[i]).norm() / ref[i].norm())) for i in range(z.shape[0])]
+            print(f"{name:14s} {dt * 1e3:8.1f} ms for {a.batch} latents ({a.batch / dt:.3f} /s, loop only)   max|z - whole| = {same:.3e}  rel {rel:.2e}  "
+                  f"worst sample {max(per):.2e}  |z|max {float(ref.abs().max()):.2f}", flush=True)
 
 
 if __name__ == "__main__":
