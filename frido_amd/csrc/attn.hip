@@ -213,7 +213,6 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                     keep[i * 4] = v.x; keep[i * 4 + 1] = v.y; keep[i * 4 + 2] = v.z; keep[i * 4 + 3] = v.w;
                     if (d.ln_op) {
                         ln_s += (v.x + v.y) + (v.z + v.w);
-                        ln_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                         *reinterpret_cast<float4*>(s_rows + orow * ldrow + col + i * 4) = v;
                     }
                 }
@@ -250,20 +249,35 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     // ---- (r03) LayerNorm of the 16 stream rows this workgroup just wrote, as an operand: norm2 / norm3 of the transformer block
     //      (attention.py:225-226) without their own launch.  gridDim.y == 1 (validated): the workgroup owns the whole rows.
     if (d.ln_op) {
+        // two-pass statistics like layernorm_kernel (mean first, then the centred sum of squares: a row with |mean| >> sigma would
+        // lose its variance in E[x^2] - mean^2); the parked rows make the second pass an LDS read of this lane's own values
         ln_s += __shfl_xor(ln_s, 1, 64); ln_s += __shfl_xor(ln_s, 2, 64);      // the four lanes of a row
-        ln_q += __shfl_xor(ln_q, 1, 64); ln_q += __shfl_xor(ln_q, 2, 64);
         __syncthreads();                            // every wave is done with its transpose slab: s_part is free
-        if ((lane & 3) == 0) {
-            s_part[(wave * 16 + orow) * 2] = ln_s;
-            s_part[(wave * 16 + orow) * 2 + 1] = ln_q;
-        }
+        if ((lane & 3) == 0) s_part[(wave * 16 + orow) * 2] = ln_s;
         __syncthreads();
-        float S = 0.f, Q = 0.f;
+        float S = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { S += s_part[(w * 16 + orow) * 2]; Q += s_part[(w * 16 + orow) * 2 + 1]; }      // fixed order
+        for (int w = 0; w < NW; ++w) S += s_part[(w * 16 + orow) * 2];          // fixed order
         const float mean = S / d.dv;
-        const float var = fmaxf(Q / d.dv - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + d.ln_eps);
+        ln_q = 0.f;
+        for (int tb = t0; tb < t1; tb += G) {
+            const int ng = t1 - tb < G ? t1 - tb : G;
+            if (oc >= ng * 16) continue;
+            const float* xq = s_rows + orow * ldrow + tb * 16 + oc;
+#pragma unroll
+            for (int i = 0; i < CPL / 4; ++i) {
+                const float4 x = *reinterpret_cast<const float4*>(xq + i * 4);
+                const float a0 = x.x - mean, a1 = x.y - mean, a2 = x.z - mean, a3 = x.w - mean;
+                ln_q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        ln_q += __shfl_xor(ln_q, 1, 64); ln_q += __shfl_xor(ln_q, 2, 64);
+        if ((lane & 3) == 0) s_part[(wave * 16 + orow) * 2 + 1] = ln_q;
+        __syncthreads();
+        float Q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) Q += s_part[(w * 16 + orow) * 2 + 1];
+        const float rstd = 1.0f / sqrtf(Q / d.dv + d.ln_eps);
         // second pass over the values this lane parked in LDS
         const float* xr = s_rows + orow * ldrow;
         frido_bf16* dst = d.ln_op + (int64_t)(row0 + orow) * d.ld_ln;

@@ -472,7 +472,7 @@ def test_attention_core_stream_output(nsplit, B, Nq, Nk, d):
     >= 256 workgroups the bf16x3 kernel also returns the LayerNorm of its rows (norm2 / norm3, attention.py:225-226)."""
     from frido_amd.engine import pack_matrix
     q, k, v = _t("aq", B, Nq, d), _t("ak", B, Nk, d), _t("av", B, Nk, d)
-    bias, res = _t("ab", d), _t("ar", B * Nq, d) + 0.3
+    bias, res = _t("ab", d), _t("ar", B * Nq, d) + (20.0 if d == 576 else 0.3)      # d = 576: rows with |mean| >> sigma (two-pass variance)
     lw, lb = 1 + 0.2 * _t("lw", d), 0.1 * _t("lb", d)
     b = _builder(nsplit, {"ln.weight": lw.cuda(), "ln.bias": lb.cuda()})
     qo = pack_matrix(q.reshape(B * Nq, d).cuda(), nsplit)
