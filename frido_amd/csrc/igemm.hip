@@ -1126,26 +1126,34 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
         for (int ks = 0; ks < KS; ++ks) {
             const int fs = ks ? fslot1 : fslot0;
             const unsigned sa = a_frag + buf * STAGE + fs, sbb = b_frag + buf * STAGE + fs;
+            // fragment reads in the order of their first use (LDS returns in order): the first weight fragment, then the pixel
+            // fragments slab by slab, then the second weight fragment -- the MFMAs of slab i start as soon as ITS fragments are back
+            // (r03; before, the first MFMA of a k-step waited for all TM * NS + NS reads of a wave, with all eight waves of the
+            // workgroup reading at once right after the barrier)
             bf16x8 fa[NS][TM];
-#pragma unroll
-            for (int p = 0; p < NS; ++p)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[p][i] = lds_read128(sa + p * PLANE + i * 16 * ROWB);
             bf16x8 fb[2][NS];
 #pragma unroll
             for (int p = 0; p < NS; ++p) fb[0][p] = lds_read128(sbb + p * PLANE);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) fa[p][i] = lds_read128(sa + p * PLANE + i * 16 * ROWB);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (j + 1 < TN) {
 #pragma unroll
                     for (int p = 0; p < NS; ++p) fb[(j + 1) & 1][p] = lds_read128(sbb + p * PLANE + (j + 1) * 16 * ROWB);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS) : "memory");
+                    if (j > 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS) : "memory");
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (j > 0 || TN == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    if (j == 0 && TN > 1) {     // outstanding after slab i's fragments: the later slabs' + the prefetched weight fragment
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS * (TM - 1 - i) + NS) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     // weights first: the accumulator tile is C^T (a lane owns 4 consecutive channels of one pixel)
                     if (NS == 2) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][0], fa[1][i], acc[i][j], 0, 0, 0);
