@@ -57,6 +57,26 @@ def test_bad_descriptors_are_rejected_without_touching_a_device():
     assert b"multiple of 32" in L.frido_last_error()
     kind, st = _lib.make_op("FRIDO_OP_SOFTMAX", rows=4, N=5000, Npad=5024)
     assert L.frido_softmax(C.addressof(st), None) == -1
+    # the LayerNorm output of the short-key attention kernel needs workgroups that own whole rows (>= 256 of them)
+    kind, st = _lib.make_op("FRIDO_OP_ATTN_SMALL", Q=64, K=64, VT=64, out_act=64, ln_op=64, ln_w=64, ln_b=64, B=2, Nq=64, Nk=26, d=384, dv=384,
+                            ldq=384, ldk=384, ldvt=32, ld_act=384, ldr=384, ld_ln=384, nsplit=2)
+    assert L.frido_attn_small(C.addressof(st), None) == -1
+    assert b"ln_op" in L.frido_last_error()
+
+
+def test_split_k_workspace_sizing_is_a_host_function():
+    """frido_gemm_workspace_bytes (include/frido_hip.h): 0 without split-K; 64 KiB of arrival tickets + splitk * M * N floats for the
+    two-kernel reduction; whole tiles (M, N padded to the family's largest tile edges) for the in-kernel reduction."""
+    import ctypes as C
+    from frido_amd import _lib
+    L = _lib.lib()
+    st = _lib.STRUCTS["FridoGemm"]()
+    st.M, st.N, st.K, st.splitk = 1000, 960, 8640, 1
+    assert L.frido_gemm_workspace_bytes(C.addressof(st)) == 0
+    st.splitk = 8
+    assert L.frido_gemm_workspace_bytes(C.addressof(st)) == 65536 + 8 * 1000 * 960 * 4
+    st.sk_mode = 1
+    assert L.frido_gemm_workspace_bytes(C.addressof(st)) == 65536 + 8 * 1024 * 1152 * 4
 
 
 def test_reference_targets_resolve_and_state_dict_layout():
