@@ -27,7 +27,7 @@ sys.path.insert(0, REPO)
 # results are bitwise repeatable and no time goes into re-tuning; a rebuilt library (different size) starts a new cache
 os.environ.setdefault("FRIDO_TUNE_CACHE", os.path.join(REPO, "profiles", "tune_cache.json"))
 
-from frido_amd import configs, synth  # noqa: E402
+from frido_amd import _lib, configs, synth  # noqa: E402
 
 
 def build_model(precision, device):
@@ -281,7 +281,10 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (hi/lo bf16 operand planes, 3 MFMA passes, fp32 accumulate: fp32-class)",
+            "dtype": "bf16" if args.precision == "bf16" else (
+                "f16x3 (precision keyword bf16x3: hi/lo fp16 operand planes, 3 MFMA passes, fp32 accumulate: fp32-class)"
+                if _lib.lib().frido_x3_plane_format() == 1 else
+                "bf16x3 (hi/lo bf16 operand planes, 3 MFMA passes, fp32 accumulate: fp32-class)"),
             "data": "synthetic (random-init weights from the deterministic filler, N(0,1) context, Philox x_T/noise)",
             "config": {"workload": f"layout2i f8f4 (configs/frido/layout2i/frido_f8f4_coco_seg.yaml), per-GPU batch {B}, "
                                    f"DDIM-{args.ddim_steps} eta=1.0 x 2 stages + MS-VQGAN decode"

@@ -21,10 +21,10 @@ __device__ __forceinline__ bf16x8 ldg8(const frido_bf16* p) { return *reinterpre
 template <int NS>
 __device__ __forceinline__ f32x4 mma(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x4 acc) {
     if (NS == 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = mfma_op<NS>(a[1], b[0], acc);
+        acc = mfma_op<NS>(a[0], b[1], acc);
     }
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return mfma_op<NS>(a[0], b[0], acc);
 }
 
 // NW waves per workgroup (4 when the grid alone fills the chip, 8 / 16 on the small planes where only more waves per
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
             const int c = lane + h * 64;
             if (c < npad) {
                 uint32_t hi, lo;
-                split_bf16(v[h] * inv, hi, lo);
+                split_op(v[h] * inv, NS, hi, lo);
                 s_p[row * P_LD + c] = (frido_bf16)hi;
                 if (NS == 2) s_p[16 * P_LD + row * P_LD + c] = (frido_bf16)lo;
             }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                     for (int i = 0; i < CPL / 8; ++i) {
                         uint32_t h[8], l[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) split_bf16(keep[i * 8 + e], h[e], l[e]);
+                        for (int e = 0; e < 8; ++e) split_op(keep[i * 8 + e], NS, h[e], l[e]);
                         *reinterpret_cast<uint4*>(dst + i * 8) =
                             make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                         if (NS == 2)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                 for (int i = 0; i < CPL / 8; ++i) {
                     uint32_t h[8], l[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) split_bf16(src[i * 8 + e], h[e], l[e]);
+                    for (int e = 0; e < 8; ++e) split_op(src[i * 8 + e], NS, h[e], l[e]);
                     *reinterpret_cast<uint4*>(dst + i * 8) =
                         make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                     if (NS == 2)
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                                     (x1.z - mean) * rstd * w1.z + b1.z, (x1.w - mean) * rstd * w1.w + b1.w};
                 uint32_t h[8], l[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+                for (int e = 0; e < 8; ++e) split_op(y[e], NS, h[e], l[e]);
                 *reinterpret_cast<uint4*>(dst + c) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 *reinterpret_cast<uint4*>(dst + d.ln_lo + c) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }

@@ -36,10 +36,34 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-// split v into hi (bf16) and lo (bf16 of the residual): v ~= hi + lo to ~2^-17 relative
-__device__ __forceinline__ void split_bf16(float v, uint32_t& hi, uint32_t& lo) {
-    hi = f32_to_bf16_bits(v);
-    lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+// ---- operand planes.  One-plane (throughput) mode: bf16.  Two-plane (parity, "x3") mode, r03: FP16 hi + FP16 lo planes --
+//      v ~= hi + lo to 2^-22 relative (bf16 pairs: 2^-17) at the same bytes and the same three MFMA passes
+//      (v_mfma_f32_16x16x32_f16 runs at the bf16 rate; gfx950 MFMA keeps fp16 denormals, which the lo plane of |v| < 0.25 needs);
+//      fp16's range (|v| <= 65504) holds every operand of the path: normalised activations, probabilities, weights, latents.
+//      -DFRIDO_X3_F16=0 builds the bf16-pair form of rounds 1-2.
+#ifndef FRIDO_X3_F16
+#define FRIDO_X3_F16 1
+#endif
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f); }   // v_cvt_f16_f32: RNE
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+// split v into the hi / lo planes of an `ns`-plane operand (ns == 1: hi = bf16, lo unused)
+__device__ __forceinline__ void split_op(float v, int ns, uint32_t& hi, uint32_t& lo) {
+    if (FRIDO_X3_F16 && ns == 2) {
+        hi = f32_to_f16_bits(v);
+        lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+    } else {
+        hi = f32_to_bf16_bits(v);
+        lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+    }
+}
+// one MFMA pass on operand fragments of an NS-plane operand format
+template <int NS>
+__device__ __forceinline__ f32x4 mfma_op(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (NS == 2 && FRIDO_X3_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
@@ -74,7 +98,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void store_op4(frido_bf16* op, int64_t lo_off, int nsplit, int64_t idx, const float v[4]) {
     uint32_t h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_bf16(v[i], h[i], l[i]);
+    for (int i = 0; i < 4; ++i) split_op(v[i], nsplit, h[i], l[i]);
     uint2 ph = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     *reinterpret_cast<uint2*>(op + idx) = ph;
     if (nsplit == 2) {
@@ -84,7 +108,7 @@ __device__ __forceinline__ void store_op4(frido_bf16* op, int64_t lo_off, int ns
 }
 __device__ __forceinline__ void store_op1(frido_bf16* op, int64_t lo_off, int nsplit, int64_t idx, float v) {
     uint32_t h, l;
-    split_bf16(v, h, l);
+    split_op(v, nsplit, h, l);
     op[idx] = (frido_bf16)h;
     if (nsplit == 2) op[lo_off + idx] = (frido_bf16)l;
 }

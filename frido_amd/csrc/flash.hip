@@ -49,10 +49,10 @@ __device__ __forceinline__ void wait_lgkm() {
 template <int NS>
 __device__ __forceinline__ f32x4 mma3(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x4 acc) {
     if constexpr (NS == 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = mfma_op<NS>(a[1], b[0], acc);
+        acc = mfma_op<NS>(a[0], b[1], acc);
     }
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return mfma_op<NS>(a[0], b[0], acc);
 }
 
 __device__ __forceinline__ float xor_max(float v) {
@@ -245,12 +245,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
                     // hi*lo, lo*hi, hi*hi of the two score fragments interleaved: consecutive MFMAs never share an accumulator
                     const bf16x8(&ka)[2] = kf[ks & 1][0];
                     const bf16x8(&kb)[2] = kf[ks & 1][1];
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1], qf[ks][0], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[1], qf[ks][0], s1, 0, 0, 0);
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0], qf[ks][1], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[0], qf[ks][1], s1, 0, 0, 0);
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0], qf[ks][0], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[0], qf[ks][0], s1, 0, 0, 0);
+                    s0 = mfma_op<NS>(ka[1], qf[ks][0], s0);
+                    s1 = mfma_op<NS>(kb[1], qf[ks][0], s1);
+                    s0 = mfma_op<NS>(ka[0], qf[ks][1], s0);
+                    s1 = mfma_op<NS>(kb[0], qf[ks][1], s1);
+                    s0 = mfma_op<NS>(ka[0], qf[ks][0], s0);
+                    s1 = mfma_op<NS>(kb[0], qf[ks][0], s1);
                 } else {
                     s0 = mma3<NS>(kf[ks & 1][0], qf[ks], s0);
                     s1 = mma3<NS>(kf[ks & 1][1], qf[ks], s1);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
         {
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) split_bf16(pv[i], h[i], l[i]);
+            for (int i = 0; i < 8; ++i) split_op(pv[i], NS, h[i], l[i]);
             u32x4 ph = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
             pf[0] = __builtin_bit_cast(bf16x8, ph);
             if constexpr (NS == 2) {
@@ -344,12 +344,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
                 } else {
                     wait_lgkm<0>();
                 }
-                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][1], pf[0], o[c], 0, 0, 0);
-                o[c + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][1], pf[0], o[c + 1], 0, 0, 0);
-                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][0], pf[1], o[c], 0, 0, 0);
-                o[c + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][0], pf[1], o[c + 1], 0, 0, 0);
-                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][0], pf[0], o[c], 0, 0, 0);
-                o[c + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][0], pf[0], o[c + 1], 0, 0, 0);
+                o[c] = mfma_op<NS>(vf[cur][0][1], pf[0], o[c]);
+                o[c + 1] = mfma_op<NS>(vf[cur][1][1], pf[0], o[c + 1]);
+                o[c] = mfma_op<NS>(vf[cur][0][0], pf[1], o[c]);
+                o[c + 1] = mfma_op<NS>(vf[cur][1][0], pf[1], o[c + 1]);
+                o[c] = mfma_op<NS>(vf[cur][0][0], pf[0], o[c]);
+                o[c + 1] = mfma_op<NS>(vf[cur][1][0], pf[0], o[c + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -384,7 +384,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                         } else {
                             uint32_t h[8], l[8];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+                            for (int e = 0; e < 8; ++e) split_op(v[e], NS, h[e], l[e]);
                             frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + ncol0 + 32 * J;
                             *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                             *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
@@ -509,7 +509,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
                 uint32_t h[8], l[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_bf16(ov[e], h[e], l[e]);
+                for (int e = 0; e < 8; ++e) split_op(ov[e], NS, h[e], l[e]);
                 frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + no;
                 *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 if (d.nsplit == 2)
@@ -611,7 +611,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
             if (d.out_op) {
                 uint32_t h[8], l[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+                for (int e = 0; e < 8; ++e) split_op(v[e], NS, h[e], l[e]);
                 frido_bf16* op = d.out_op + oo_base + out_row(m) * d.ldoo + n;
                 *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 if (d.nsplit == 2)
@@ -922,7 +922,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[P][i], acc[i][j], 0, 0, 0);   // weights first: C^T tiles
+                    acc[i][j] = mfma_op<NS>(fb[P][j], fa[P][i], acc[i][j]);   // weights first: C^T tiles
                 __builtin_amdgcn_sched_barrier(0);
                 if (dma) {
                     static_for<j * NPC / TN, (j + 1) * NPC / TN>([&](auto qc) { issue_piece(qc, buf); });
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
                     if constexpr (FRIDO_ABLATE & 128) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[BS][j], fa[AS][i], acc[i][j], 0, 0, 0);   // weights first: C^T tiles
+                        acc[i][j] = mfma_op<NS>(fb[BS][j], fa[AS][i], acc[i][j]);   // weights first: C^T tiles
                     if constexpr (FRIDO_ABLATE & 128) __builtin_amdgcn_s_setprio(0);
                 } else {
                     asm volatile("" :: "v"(fb[BS][j]), "v"(fa[AS][0]), "v"(fa[AS][TM - 1]));      // keep the fragment reads alive
@@ -1156,10 +1156,10 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
                     }
                     // weights first: the accumulator tile is C^T (a lane owns 4 consecutive channels of one pixel)
                     if (NS == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][0], fa[1][i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][1], fa[0][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_op<NS>(fb[j & 1][0], fa[1][i], acc[i][j]);
+                        acc[i][j] = mfma_op<NS>(fb[j & 1][1], fa[0][i], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1][0], fa[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_op<NS>(fb[j & 1][0], fa[0][i], acc[i][j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1805,7 +1805,7 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) 
         if (d.out_op) {
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split_bf16(v[e], h[e], l[e]);
+            for (int e = 0; e < 8; ++e) split_op(v[e], d.nsplit, h[e], l[e]);
             frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + n;
             *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             if (d.nsplit == 2)

@@ -285,12 +285,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
             }
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+            for (int e = 0; e < 8; ++e) split_op(y[e], 2, h[e], l[e]);
             *reinterpret_cast<uint4*>(d.out_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             *reinterpret_cast<uint4*>(d.out_op + d.out_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             if (d.raw_op) {                 // concatenated raw operand for the 1x1 skip conv
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_bf16(xin[e], h[e], l[e]);
+                for (int e = 0; e < 8; ++e) split_op(xin[e], 2, h[e], l[e]);
                 *reinterpret_cast<uint4*>(d.raw_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 *reinterpret_cast<uint4*>(d.raw_op + d.raw_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
@@ -577,13 +577,13 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
         }
         uint32_t h[8], l[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+        for (int e = 0; e < 8; ++e) split_op(y[e], d.nsplit, h[e], l[e]);
         *reinterpret_cast<u32x4*>(d.out_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         if (d.nsplit == 2)
             *reinterpret_cast<u32x4*>(d.out_op + d.out_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
         if (d.raw_op) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split_bf16(xv[k][e], h[e], l[e]);
+            for (int e = 0; e < 8; ++e) split_op(xv[k][e], d.nsplit, h[e], l[e]);
             *reinterpret_cast<u32x4*>(d.raw_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
             if (d.nsplit == 2)
                 *reinterpret_cast<u32x4*>(d.raw_op + d.raw_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};

@@ -273,6 +273,7 @@ extern "C" int frido_init(void) {
 }
 
 extern "C" int frido_abi_version(void) { return 1; }
+extern "C" int frido_x3_plane_format(void) { return FRIDO_X3_F16 ? 1 : 0; }
 extern "C" int frido_sizeof_op(void) { return (int)sizeof(FridoOp); }
 extern "C" int frido_sizeof_desc(int32_t kind) {
     switch (kind) {

@@ -25,15 +25,23 @@ def rup(x, m):
     return (x + m - 1) // m * m
 
 
+def plane_dtype(nsplit):
+    """torch dtype of an operand plane: bf16 for one-plane operands; for the two-plane (bf16x3 precision) operands whatever the
+    library was built for (frido_x3_plane_format: fp16 hi + fp16 lo since r03, bf16 pairs before)."""
+    if nsplit == 2 and _lib.lib().frido_x3_plane_format() == 1:
+        return torch.float16
+    return torch.bfloat16
+
+
 class Operand:
-    """bf16 operand matrix [rows][K] (K contiguous) with `nsplit` planes; plane p starts p*lo elements in."""
+    """operand matrix [rows][K] (K contiguous) of 16-bit elements with `nsplit` planes (plane_dtype); plane p starts p*lo elements in."""
 
     def __init__(self, rows, K, nsplit, device, zero=False, batch=1):
         self.rows, self.K, self.nsplit, self.batch = rows, K, nsplit, batch
         n = batch * rows * K
         self.lo = rup(n, 8)
         alloc = torch.zeros if zero else torch.empty
-        self.t = alloc((nsplit, self.lo), dtype=torch.bfloat16, device=device)
+        self.t = alloc((nsplit, self.lo), dtype=plane_dtype(nsplit), device=device)
 
     @property
     def ptr(self):
@@ -57,11 +65,12 @@ def pack_matrix(w2d, nsplit, kpad=32):
     Kp = rup(K, kpad)
     op = Operand(N, Kp, nsplit, w2d.device, zero=True)
     w = w2d.float()
-    hi = w.to(torch.bfloat16)
+    dt = plane_dtype(nsplit)
+    hi = w.to(dt)
     view = op.t[0, :N * Kp].view(N, Kp)
     view[:, :K] = hi
     if nsplit == 2:
-        op.t[1, :N * Kp].view(N, Kp)[:, :K] = (w - hi.float()).to(torch.bfloat16)
+        op.t[1, :N * Kp].view(N, Kp)[:, :K] = (w - hi.float()).to(dt)
     return op
 
 
@@ -172,7 +181,7 @@ class POperand:
 
     def to_f32(self):
         n = self.batch * self.rows * self.K
-        t = self.buf[: self.nsplit * self.lo * 2].view(torch.bfloat16).view(self.nsplit, self.lo)
+        t = self.buf[: self.nsplit * self.lo * 2].view(plane_dtype(self.nsplit)).view(self.nsplit, self.lo)
         v = t[0, :n].float()
         if self.nsplit == 2:
             v = v + t[1, :n].float()

@@ -392,6 +392,10 @@ int frido_init(void);
 
 /* ---- introspection ---- */
 int frido_abi_version(void);
+/* Element format of the planes of a TWO-plane (nsplit = 2, "bf16x3" precision) operand: 0 = bf16 hi + bf16 lo (rounds 1-2),
+ * 1 = fp16 hi + fp16 lo (r03 default: 22 mantissa bits at the same bytes and MFMA passes).  One-plane operands are always bf16.
+ * A host that packs weights / operands itself (hi = round(v), lo = round(v - hi) in this format) asks here. */
+int frido_x3_plane_format(void);
 int frido_sizeof_op(void);             /* sizeof(FridoOp): checked by the ctypes mirror */
 int frido_sizeof_desc(int32_t kind);   /* sizeof of the descriptor struct of that op kind */
 const char* frido_last_error(void);
