@@ -1,9 +1,11 @@
 """Model-level parity on the MI355X: the HIP path behind the reference's class API against (a) the
 golden fixtures captured from the reference itself and (b) the oracle on the same seeded inputs.
 
-Precision: bf16x3 (fp32-emulating MFMA path).  Stated tolerances, relative to the output's max-abs:
+Precision: bf16x3 keyword = the fp32-emulating MFMA path (r03: fp16 hi + fp16 lo operand planes, three passes).  Stated tolerances,
+relative to the output's max-abs:
   single denoiser forward     2e-4      multi-step sampler latents   1e-3
-  VQGAN decode (same codes)   2e-4      decoded pixels end-to-end    1e-3 abs (north star), code flips reported
+  VQGAN decode (same codes)   2e-4      decoded pixels end-to-end    1e-3 abs (north star); the full-size end-to-end runs assert
+                                        E2E_X3 below (latent 5e-5, pixels 1e-4, measured 6e-6 / 8e-6), code flips reported
 """
 import os
 
@@ -637,15 +639,20 @@ def test_config1_full_width_end_to_end(run, S, precision):
         # north star: <= 1e-3 max-abs on decoded pixels.  Unconditional for the decoder (reference latent + codes); end to end
         # it holds wherever no VQ code flipped -- one flipped code (a discontinuity) reaches every pixel through the decoder's
         # four global attention blocks, so with flips only their rate is asserted
-        assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+        assert rep["latent_rel"] < E2E_X3["latent_rel"] and rep["vq_flip_rate"] < E2E_X3["vq_flip_rate"] and rep["forced_pix_max"] < E2E_X3["pix_max"]
         if rep["vq_flip_rate"] == 0:
-            assert rep["pix_max"] < 1e-3
+            assert rep["pix_max"] < E2E_X3["pix_max"]
     else:
         assert rep["latent_rel"] < E2E_BF16["latent_rel"] and rep["vq_flip_rate"] < E2E_BF16["vq_flip_rate"]
         assert rep["pix_p50"] < E2E_BF16["pix_p50"] and rep["pix_p99"] < E2E_BF16["pix_p99"]
         assert rep["forced_pix_max"] < E2E_BF16["forced_pix_max"]
 
 
+# bounds of the parity arithmetic end to end (r03: fp16 hi + fp16 lo operand planes), = measured value x ~10: latent rel 2.4e-6 - 5.8e-6
+# (the fp32 oracle itself: 1.7e-6 - 2.1e-6), 0 flipped VQ codes in every run, decoded pixels <= 8.3e-6 max-abs end to end and
+# 6 - 8e-6 for the decoder alone (profiles/r03_e2e_error.json).  The north star asks <= 1e-3.  A flipped code is still tolerated at a rate
+# (a decision boundary is a discontinuity: the fp32 oracle is not immune in principle), but the pixel bound applies whenever none flips.
+E2E_X3 = dict(latent_rel=5e-5, vq_flip_rate=5e-4, pix_max=1e-4)
 # bounds of the bf16 (benchmark) arithmetic end to end, = measured value x ~2 (see DESIGN.md §5 for the measurements)
 # r02 measurements (gpurun_out/t_r02a.log): latent rel 0.85-1.2e-2, VQ flips 0.8-1.6 %, pixel error p50 1.4-2.1e-2 /
 # p99 0.21-0.28, decoder alone on identical codes 2.9-3.4e-2 max-abs
@@ -679,9 +686,9 @@ def test_config3_t2i_true_dims_plms_cfg(precision):
         assert len(inter["x_inter"]) == int(g[f"{run}_nx"])
         rep = _e2e_report(f"config3/{run}/{precision}", model, g, run, samples, [4, 4])
         if precision == "bf16x3":
-            assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+            assert rep["latent_rel"] < E2E_X3["latent_rel"] and rep["vq_flip_rate"] < E2E_X3["vq_flip_rate"] and rep["forced_pix_max"] < E2E_X3["pix_max"]
             if rep["vq_flip_rate"] == 0:
-                assert rep["pix_max"] < 1e-3
+                assert rep["pix_max"] < E2E_X3["pix_max"]
         else:
             assert rep["latent_rel"] < E2E_BF16["latent_rel"] and rep["forced_pix_max"] < E2E_BF16["forced_pix_max"]
 
@@ -751,9 +758,9 @@ def test_config5_three_stage_multistep_at_true_size():
     assert rec.n == int(g["ddim2_noise_n"]) and abs(rec.sum - float(g["ddim2_noise_sum"])) < 1e-6 * rec.n
     assert len(inter["x_inter"]) == int(g["ddim2_nx"])
     rep = _e2e_report("config5/ddim2x3stages/bf16x3", model, g, "ddim2", samples, [3, 3, 3])
-    assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+    assert rep["latent_rel"] < E2E_X3["latent_rel"] and rep["vq_flip_rate"] < E2E_X3["vq_flip_rate"] and rep["forced_pix_max"] < E2E_X3["pix_max"]
     if rep["vq_flip_rate"] == 0:
-        assert rep["pix_max"] < 1e-3
+        assert rep["pix_max"] < E2E_X3["pix_max"]
 
 
 def test_config2_step_count_ddim200_end_to_end():
@@ -770,9 +777,9 @@ def test_config2_step_count_ddim200_end_to_end():
     assert rec.n == int(g["ddim200_noise_n"]) and abs(rec.sum - float(g["ddim200_noise_sum"])) < 1e-6 * rec.n
     assert len(inter["x_inter"]) == int(g["ddim200_nx"])
     rep = _e2e_report("config2-steps/ddim200/bf16x3", model, g, "ddim200", samples, [3, 3])
-    assert rep["latent_rel"] < 1e-3 and rep["vq_flip_rate"] < 2e-3 and rep["forced_pix_max"] < 1e-3
+    assert rep["latent_rel"] < E2E_X3["latent_rel"] and rep["vq_flip_rate"] < E2E_X3["vq_flip_rate"] and rep["forced_pix_max"] < E2E_X3["pix_max"]
     if rep["vq_flip_rate"] == 0:
-        assert rep["pix_max"] < 1e-3
+        assert rep["pix_max"] < E2E_X3["pix_max"]
 
 
 def test_bench_under_torchrun_takes_the_rccl_path_at_n1():
