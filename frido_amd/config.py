@@ -1,8 +1,8 @@
 """Process-wide knobs of the HIP path."""
 import os
 
-# "bf16x3": operands carry hi+lo bf16 planes, 3 MFMAs per product, ~2^-17 relative error (fp32-class;
-#           the mode the parity tests pin against the fp32 oracle);
+# "bf16x3": operands carry hi + lo planes, 3 MFMAs per product -- fp16 planes since r03 (~2^-22 relative error; the keyword is
+#           kept from the bf16-pair rounds, ~2^-17), fp32-class: the mode the parity tests pin against the fp32 oracle;
 # "bf16":   single bf16 plane, 1 MFMA per product (the throughput mode BASELINE.json config 2 names).
 PRECISION = os.environ.get("FRIDO_PRECISION", "bf16x3")
 

@@ -9,10 +9,13 @@
  *   - every launcher returns 0 on success, a negative FRIDO_E* code on bad arguments or a HIP
  *     error (never throws, never exits); kernels are enqueued on the caller's hipStream_t and
  *     are hipGraph-capturable (no allocation, no synchronisation inside);
- *   - activations are NHWC fp32 ("f32") or NHWC bf16 "operand" tensors.  An operand tensor is
- *     a bf16 matrix [rows][K] with K contiguous; in bf16x3 mode (nsplit == 2) a second bf16
- *     plane holding the rounding residual lives `lo` elements after the first, and products are
- *     accumulated as hi*hi + hi*lo + lo*hi in fp32 on the MFMA pipe (≈2^-17 relative error).
+ *   - activations are NHWC fp32 ("f32") or NHWC 16-bit "operand" tensors.  An operand tensor is
+ *     a matrix [rows][K] of 16-bit elements with K contiguous (`frido_bf16` in the signatures is
+ *     the 16-bit storage type).  One-plane mode (nsplit == 1): bf16.  Two-plane mode (nsplit == 2,
+ *     the "bf16x3" precision keyword): a second plane holding the rounding residual lives `lo`
+ *     elements after the first, products are accumulated as hi*hi + hi*lo + lo*hi in fp32 on the
+ *     MFMA pipe; both planes are fp16 (frido_x3_plane_format() == 1: ≈2^-22 relative error) or,
+ *     in a -DFRIDO_X3_F16=0 build, bf16 (≈2^-17).
  */
 #ifndef FRIDO_HIP_H
 #define FRIDO_HIP_H
