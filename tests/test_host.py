@@ -79,6 +79,20 @@ def test_split_k_workspace_sizing_is_a_host_function():
     assert L.frido_gemm_workspace_bytes(C.addressof(st)) == 65536 + 8 * 1024 * 1152 * 4
 
 
+def test_operand_plane_format_and_host_packer_agree():
+    """Two-plane operands: the host packer (engine.pack_matrix) splits in the format the library multiplies in
+    (frido_x3_plane_format: fp16 pairs = 22 mantissa bits, bf16 pairs = 16); one-plane operands are bf16."""
+    from frido_amd import _lib
+    from frido_amd.engine import pack_matrix, plane_dtype
+    fmt = _lib.lib().frido_x3_plane_format()
+    assert fmt in (0, 1) and plane_dtype(1) == torch.bfloat16 and plane_dtype(2) == (torch.float16 if fmt else torch.bfloat16)
+    w = torch.randn(37, 50, generator=torch.Generator().manual_seed(5)) * 3
+    two, one = pack_matrix(w, 2), pack_matrix(w, 1)
+    assert two.K == 64 and float(two.to_f32()[:, 50:].abs().max()) == 0.0            # K zero-padded to 32
+    rel = lambda o: float(((o.to_f32()[:, :50] - w).abs() / w.abs().clamp_min(0.25)).max())
+    assert rel(two) < (2.0 ** -20 if fmt else 2.0 ** -15) and 2.0 ** -12 < rel(one) < 2.0 ** -7
+
+
 def test_reference_targets_resolve_and_state_dict_layout():
     from frido_amd.models import instantiate_from_config
     import frido.models.diffusion.frido as F
