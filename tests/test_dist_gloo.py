@@ -99,3 +99,41 @@ def test_sample_images_shard_logic_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def _bench_line(args, env_extra, timeout=300):
+    env = dict(os.environ, FRIDO_BENCH_STUB="1", **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env,
+                         timeout=timeout, cwd=REPO)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # ONE JSON line, printed by rank 0 only
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2 ...` typed WITHOUT torch.distributed.run (the driver's N = 1 spelling with a larger N) re-execs
+    itself as a 2-rank job and prints one whole-job JSON line; FRIDO_BENCH_STUB swaps the HIP sampler for a CPU function of the
+    global sample index so the launcher, shard arithmetic, barrier-bracketed timing and max-over-ranks run here over gloo."""
+    line = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5"], {})
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["stub"] is True
+    assert line["config"]["global_batch"] == 10 and line["scaling"] == "weak" and len(line["per_rank_ms_per_step"]) == 2
+    assert abs(line["value"] - 10 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-3       # whole-job aggregate
+    assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 0.02                       # slowest rank sets the time
+
+
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """The driver's own N > 1 spelling: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    env = dict(os.environ, FRIDO_BENCH_STUB="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29523", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=REPO)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert sum(l.startswith("{") for l in out.stdout.splitlines()) == 1
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29524", os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=REPO)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stdout + bad.stderr      # a mismatch is an error message, not a traceback
