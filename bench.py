@@ -309,6 +309,9 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=200)
     ap.add_argument("--precision", default=os.environ.get("FRIDO_PRECISION", "bf16x3"), choices=["bf16", "bf16x3"],
                     help="bf16x3 (default) = the arithmetic of the <= 1e-3 parity tests; bf16 = throughput mode, fails that tolerance")
+    ap.add_argument("--image-dtype", default="uint8", choices=["uint8", "float32"],
+                    help="what a step hands back (and, N > 1, all-gathers): the uint8 HWC images of scripts/sample_diffusion.py "
+                         "custom_to_np, written by the decoder's last epilogue (default), or decode_first_stage's f32 NCHW tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-extra", "--no-parity-mode", dest="no_bf16_extra", action="store_true",
                     help="skip the extra bf16 (throughput-mode) pass at N = 1")
@@ -321,6 +324,10 @@ def main():
     if debug_env and not args.allow_debug:
         sys.exit(f"bench.py: {debug_env} drop work from the timed region; pass --allow-debug for a timing experiment "
                  "(the line then carries \"debug_work_skipped\": true and is not a benchmark result)")
+    if debug_env.get("FRIDO_DEBUG_SKIP"):
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import debug_skip                                   # the work-skipping hook lives in tools/, not in the library
+        debug_skip.install()
     if not args.retune:
         os.environ.setdefault("FRIDO_TUNE_CACHE_READONLY", "1")     # the tracked cache is only rewritten on request
 
@@ -360,7 +367,8 @@ def main():
     ctx = torch.from_numpy(ctx_all[lo:hi]).to(dev)
 
     def one_step(k):
-        return sample_images(model, ctx, S=args.ddim_steps, eta=1.0, seed=1000 + k, sample0=lo, noise="philox", total=total)
+        return sample_images(model, ctx, S=args.ddim_steps, eta=1.0, seed=1000 + k, sample0=lo, noise="philox", total=total,
+                             gather_dtype=args.image_dtype)
 
     for k in range(args.warmup):
         one_step(k)
@@ -383,18 +391,19 @@ def main():
         dist.all_gather(allt, torch.tensor([dt], device=dev, dtype=torch.float64))
         per_rank = [float(t.item()) for t in allt]
         dt = max(per_rank)                      # the slowest rank sets the job's time
-    assert img.shape == (total, 3, 256, 256)
-    assert bool(torch.isfinite(img).all()) or debug_env
+    assert img.shape == ((total, 256, 256, 3) if args.image_dtype == "uint8" else (total, 3, 256, 256))
+    assert args.image_dtype == "uint8" or bool(torch.isfinite(img).all()) or debug_env
     # the reference's own throughput definition (scripts/sample_diffusion.py:188-204): the sampling loop only, no decode
     from frido_amd.samplers import DDIMSampler
     unet = model.model.diffusion_model
     fence()
     t0 = time.perf_counter()
-    DDIMSampler(model).sample(S=args.ddim_steps, batch_size=B, shape=(unet.in_channels, unet.image_size, unet.image_size),
-                              conditioning=ctx, num_stage=unet.num_stage, eta=1.0, verbose=False, noise="philox", seed=999,
-                              sample0=lo, log_every_t=10 ** 9)
+    z_chk, _ = DDIMSampler(model).sample(S=args.ddim_steps, batch_size=B, shape=(unet.in_channels, unet.image_size, unet.image_size),
+                                         conditioning=ctx, num_stage=unet.num_stage, eta=1.0, verbose=False, noise="philox", seed=999,
+                                         sample0=lo, log_every_t=10 ** 9)
     fence()
     dt_loop = time.perf_counter() - t0
+    assert (bool(torch.isfinite(z_chk).all()) and float(z_chk.std()) > 0.05 and int(img.max()) > int(img.min())) or debug_env, "degenerate samples"
 
     if rank == 0:
         rt = model.model.diffusion_model.runtime()
@@ -427,7 +436,7 @@ def main():
             "data": "synthetic (random-init weights from the deterministic filler, N(0,1) context, Philox x_T/noise)",
             "config": {"workload": f"layout2i f8f4 (configs/frido/layout2i/frido_f8f4_coco_seg.yaml), per-GPU batch {B}, "
                                    f"DDIM-{args.ddim_steps} eta=1.0 x 2 stages + MS-VQGAN decode"
-                                   + (", RCCL all-gather of decoded images" if world > 1 else ""),
+                                   + f" to {args.image_dtype} images" + (f", RCCL all-gather of the {args.image_dtype} images" if world > 1 else ""),
                        "global_batch": total, "denoiser_forwards_per_step": 2 * args.ddim_steps, "parallelism": f"dp{world}",
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("FRIDO_") and k != "FRIDO_TUNE_CACHE"}},
             "roofline": roof,
@@ -445,11 +454,12 @@ def main():
             del model
             torch.cuda.empty_cache()
             m1 = build_model("bf16", dev)
-            sample_images(m1, ctx, S=args.ddim_steps, eta=1.0, seed=1, sample0=lo, noise="philox", total=total)
+            sample_images(m1, ctx, S=args.ddim_steps, eta=1.0, seed=1, sample0=lo, noise="philox", total=total, gather_dtype=args.image_dtype)
             fence()
             t0 = time.perf_counter()
             for k in range(args.steps):
-                sample_images(m1, ctx, S=args.ddim_steps, eta=1.0, seed=2 + k, sample0=lo, noise="philox", total=total)
+                sample_images(m1, ctx, S=args.ddim_steps, eta=1.0, seed=2 + k, sample0=lo, noise="philox", total=total,
+                              gather_dtype=args.image_dtype)
             fence()
             d1 = (time.perf_counter() - t0) / args.steps
             extra = {"dtype": "bf16", "value": round(total / d1, 4), "unit": "images/s", "ms_per_step": round(1e3 * d1, 2),

@@ -324,6 +324,9 @@ class Builder:
             res = self.op(M, rup(N, 32))
             assert rup(N, 32) == N, "operand outputs must have N % 32 == 0 (pad columns would be garbage)"
             kw.update(out_op=res.ptr, ldoo=res.K, oo_lo=res.lo)
+        elif isinstance(out, tuple) and out[0] == "u8":      # ("u8", uint8 tensor [M][N], mode): image output fused into the epilogue
+            _, res, mode = out
+            kw.update(out_u8=res.data_ptr(), ldu8=N, u8_mode=mode)
         elif isinstance(out, tuple):        # ("f32"|"op", existing buffer)
             kind, res = out
             if kind == "f32":

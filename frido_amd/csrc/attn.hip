@@ -321,14 +321,17 @@ bool attn_lds_optin() {
 }
 
 template <int NS>
-void launch_attn(const FridoAttnSmall& d, hipStream_t s) {
+int launch_attn(const FridoAttnSmall& d, hipStream_t s) {
     const int blocks = d.B * (d.Nq / 16);
     const bool many = blocks >= 512;                    // >= 2 workgroups per CU: the grid hides the latency chain
     const int cs = blocks >= 256 ? 1 : (blocks >= 128 ? 2 : 4);
     const size_t dyn = d.ln_op ? (size_t)16 * (d.dv + 4) * sizeof(float) : 0;      // the rows parked for their LayerNorm (<= 62 KiB at dv = 960)
 #define ATTN_LAUNCH(NW, NF)                                                                                               \
     do {                                                                                                                  \
-        if (dyn && !attn_lds_optin<NS, NW, NF>()) frido_set_error("attn_small: cannot set the dynamic LDS size");         \
+        if (dyn && !attn_lds_optin<NS, NW, NF>()) {                                                                       \
+            frido_set_error("attn_small: cannot opt in to %zu bytes of dynamic LDS", dyn);                                \
+            return FRIDO_EHIP;                  /* no launch with an under-provisioned row buffer */                      \
+        }                                                                                                                 \
         hipLaunchKernelGGL((attn_small_kernel<NS, NW, NF>), dim3(blocks, cs), dim3(NW * 64), dyn, s, d);                  \
     } while (0)
     if (d.Nk <= 32) {
@@ -339,6 +342,7 @@ void launch_attn(const FridoAttnSmall& d, hipStream_t s) {
         ATTN_LAUNCH(4, 8);
     }
 #undef ATTN_LAUNCH
+    return FRIDO_OK;
 }
 
 }  // namespace
@@ -356,7 +360,7 @@ extern "C" int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s) {
     FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && d->B * (d->Nq / 16) >= 256 && d->dv <= 1024 && d->ln_w && d->ln_b &&
                                 (d->ld_ln & 7) == 0 && (d->ln_lo & 7) == 0),
                   "ln_op: bf16x3 f32-stream output, B * Nq / 16 >= 256 (one workgroup per 16 rows owns them whole), weight and bias given");
-    if (d->nsplit == 2) launch_attn<2>(*d, (hipStream_t)s);
-    else launch_attn<1>(*d, (hipStream_t)s);
+    const int rc = d->nsplit == 2 ? launch_attn<2>(*d, (hipStream_t)s) : launch_attn<1>(*d, (hipStream_t)s);
+    if (rc != FRIDO_OK) return rc;
     return frido_check_launch("attn_small");
 }

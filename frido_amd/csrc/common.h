@@ -39,8 +39,13 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 // ---- operand planes.  One-plane (throughput) mode: bf16.  Two-plane (parity, "x3") mode, r03: FP16 hi + FP16 lo planes --
 //      v ~= hi + lo to 2^-22 relative (bf16 pairs: 2^-17) at the same bytes and the same three MFMA passes
 //      (v_mfma_f32_16x16x32_f16 runs at the bf16 rate; gfx950 MFMA keeps fp16 denormals, which the lo plane of |v| < 0.25 needs);
-//      fp16's range (|v| <= 65504) holds every operand of the path: normalised activations, probabilities, weights, latents.
-//      -DFRIDO_X3_F16=0 builds the bf16-pair form of rounds 1-2.
+//      Error of the pair: max(2^-22 |v|, 2^-25) -- the lo plane is an fp16 SUBNORMAL for |v| < 2^-3, so the absolute floor is
+//      half of fp16's smallest subnormal step (2^-24), not a relative bound, below that magnitude.
+//      Range: values beyond fp16's +-65504 are CLAMPED there by split_op (r04; they used to become inf hi / -inf lo planes and a
+//      NaN product): an out-of-range operand degrades to a saturated one instead of poisoning the image.  Normalised
+//      activations, probabilities and weights sit far inside; the un-normalised producers (raw residual stream into a 1x1
+//      skip / resample conv, GEGLU / MLP hidden activations) are the ones a trained checkpoint could push out, and a model
+//      whose operands do saturate needs the bf16-pair build: -DFRIDO_X3_F16=0 (rounds 1-2's planes, fp32's range).
 #ifndef FRIDO_X3_F16
 #define FRIDO_X3_F16 1
 #endif
@@ -50,6 +55,7 @@ __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) { return (float)__b
 // split v into the hi / lo planes of an `ns`-plane operand (ns == 1: hi = bf16, lo unused)
 __device__ __forceinline__ void split_op(float v, int ns, uint32_t& hi, uint32_t& lo) {
     if (FRIDO_X3_F16 && ns == 2) {
+        v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);       // saturate at fp16's range (one VALU op) instead of inf - inf = NaN
         hi = f32_to_f16_bits(v);
         lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
     } else {

@@ -192,7 +192,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
         const int a = (up2 - 1) >> 1, bq = (up2 - 1) & 1;
         return ((int64_t)(img * 2 * d.Ho + 2 * y + a) * (2 * d.Wo)) + 2 * x + bq;
     };
-    const bool fast = vec_ok && (d.N & 7) == 0;        // every lane's 8 columns are then all inside or all outside N
+    const bool fast = vec_ok && (d.N & 7) == 0 && !d.out_u8;      // every lane's 8 columns are then all inside or all outside N (uint8 images: element-wise path)
     const bool rv_hoist = d.rowvec && d.rows_per_vec >= (1 << 29) && !(d.flags & 2);
     // ---- direct paths (accumulators -> global) ----
     const bool plain = fast && perm && d.act == FRIDO_ACT_NONE && !d.row_bias && (!d.rowvec || rv_hoist) && !(d.flags & 16);
@@ -539,6 +539,12 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 const int64_t mo = out_row(m);
                 if (d.out_f32) store_act1(d.out_f32, of_base + mo * d.ldo + n, d.out_bf16, x);
                 if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, mo * d.ldoo + n, x);
+                if (d.out_u8) {      // sample_diffusion.py:103-121: every step its own fp32 rounding (no contraction), then truncation
+                    float u;
+                    if (d.u8_mode == 2) u = __fmul_rn(255.0f, __fmul_rn(__fadd_rn(fminf(fmaxf(x, -1.0f), 1.0f), 1.0f), 0.5f));
+                    else u = fminf(fmaxf(__fmul_rn(__fadd_rn(x, 1.0f), 127.5f), 0.0f), 255.0f);
+                    d.out_u8[mo * d.ldu8 + n] = (uint8_t)u;
+                }
             }
             continue;
         }
@@ -2021,7 +2027,10 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     FRIDO_REQUIRE(d.K2 == 0 || (d.A2 && (d.lda2 & 7) == 0 && (d.K & 63) == 0 && d.batch == 1), "bad second A operand");
     FRIDO_REQUIRE(d.nsplit == 1 || d.nsplit == 2, "nsplit must be 1 or 2");
     FRIDO_REQUIRE(d.A && d.B, "null operand");
-    FRIDO_REQUIRE(d.out_f32 || d.out_op, "no output");
+    FRIDO_REQUIRE(d.out_f32 || d.out_op || d.out_u8, "no output");
+    FRIDO_REQUIRE(!d.out_u8 || ((d.u8_mode == 1 || d.u8_mode == 2) && d.ldu8 >= d.N && d.splitk <= 1 && !d.gn_part && !d.geglu && !d.up2_phase &&
+                                d.batch == 1),
+                  "out_u8: u8_mode 1 (custom_to_np) or 2 (custom_to_pil), ldu8 >= N, no split-K / gn_part / geglu / phases / batching");
     FRIDO_REQUIRE((d.ldb & 7) == 0 && (d.b_bs & 7) == 0, "B rows must be 16-byte aligned");
     if (d.conv) {
         FRIDO_REQUIRE((d.Cin & 31) == 0 && d.Cin > 0, "conv Cin must be a multiple of 32");

@@ -272,7 +272,9 @@ extern "C" int frido_init(void) {
     return rc;
 }
 
-extern "C" int frido_abi_version(void) { return 1; }
+// 2 (r03/r04): FridoGemm gained sk_mode / gn_part (mid-struct), FridoAttnSmall / FridoSoftmax / FridoGnStats grew, the split-K
+// workspace starts with a 64-KiB ticket header the caller zeroes, two-plane operands are fp16 pairs (frido_x3_plane_format)
+extern "C" int frido_abi_version(void) { return FRIDO_ABI_VERSION; }
 extern "C" int frido_x3_plane_format(void) { return FRIDO_X3_F16 ? 1 : 0; }
 extern "C" int frido_sizeof_op(void) { return (int)sizeof(FridoOp); }
 extern "C" int frido_sizeof_desc(int32_t kind) {

@@ -66,6 +66,8 @@ def pack_matrix(w2d, nsplit, kpad=32):
     op = Operand(N, Kp, nsplit, w2d.device, zero=True)
     w = w2d.float()
     dt = plane_dtype(nsplit)
+    if dt == torch.float16:
+        w = w.clamp(-65504.0, 65504.0)      # saturate like the kernels' split_op (csrc/common.h): an inf plane would turn the product into NaN
     hi = w.to(dt)
     view = op.t[0, :N * Kp].view(N, Kp)
     view[:, :K] = hi
@@ -232,7 +234,7 @@ class Prog:
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
              residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
              oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0, A2=None, lda2=0, K2=0,
-             gn_part=None):
+             gn_part=None, out_u8=None, ldu8=0, u8_mode=0):
         """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
         ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
@@ -261,6 +263,8 @@ class Prog:
             kw.update(out_op=out_op, oo_bs=oo_bs, ldoo=ldoo, oo_lo=oo_lo)
         if gn_part is not None:
             kw["gn_part"] = gn_part
+        if out_u8 is not None:
+            kw.update(out_u8=out_u8, ldu8=ldu8, u8_mode=u8_mode)
         self.emit("FRIDO_OP_GEMM", **kw)
         if not tile and self.device.type == "cuda":
             from . import tune

@@ -12,7 +12,10 @@ from .arch import unet_arch, decoder_arch, encoder_arch
 
 
 def _p(*shape):
-    return nn.Parameter(torch.empty(*shape), requires_grad=False)
+    # requires_grad like every nn layer of the reference: LitEma shadows exactly the parameters that require grad (ema.py:16-20),
+    # so the denoiser's holders must look trainable for the `model_ema.*` keys to exist; the first stage is frozen by
+    # FridoDiffusion.instantiate_first_stage (frido.py:617-623).  Nothing here is ever differentiated: the HIP path runs under no_grad.
+    return nn.Parameter(torch.empty(*shape))
 
 
 class Conv(nn.Module):

@@ -217,12 +217,13 @@ class VQModelInterface(_Versioned, _Base):
 
     @torch.no_grad()
     def decode(self, h_in, force_not_quantize=False, return_code=False, inv_scale=None, to_uint8=False, force_codes=None):
-        """msvqgan.py:376-399.  Returns dec (B,3,H,W) [and per-scale code lists when return_code]; to_uint8 returns
-        the (B,H,W,3) uint8 image of scripts/sample_diffusion.py:115-121 straight from the decoder's NHWC output."""
+        """msvqgan.py:376-399.  Returns dec (B,3,H,W) [and per-scale code lists when return_code]; to_uint8 (True / "np" /
+        "pil") returns the (B,H,W,3) uint8 image of scripts/sample_diffusion.py:115-121 (custom_to_np) or :103-113
+        (custom_to_pil) straight from the epilogue of the decoder's last convolution."""
         if not h_in.is_cuda:
             _no_cpu("VQModelInterface.decode", h_in.device)
-        if force_not_quantize:
-            raise NotImplementedError("decode(force_not_quantize=True) is not used by the sampling path")
+        # force_not_quantize: accepted and IGNORED, exactly like the reference (msvqgan.py:376-399 never reads the flag: the
+        # multi-scale decode always quantises)
         out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code, to_uint8=to_uint8, force_codes=force_codes)
         if return_code:
             dec, idx = out
@@ -236,6 +237,24 @@ class VQModelInterface(_Versioned, _Base):
             _no_cpu("VQModelInterface.encode", x.device)
         assert len(self.channel_range) != 2, "channel_range slicing is not used by any shipped config"
         return self.runtime().encode(x, scale=scale)
+
+
+PLAN_CACHE_SIZE = 4      # compiled cond-stage plans kept per (batch, tokens) shape (like samplers.ENGINE_CACHE_SIZE)
+
+
+def _cached_plan(cache, key, builder, make):
+    """LRU of compiled plans on one Builder.  A plan is built inside `persist_scope()`, so its persistent buffers (V^T operands,
+    token / output tensors' companions) belong to the cache entry: evicting the least-recently-used shape frees their HBM
+    instead of pinning one set per batch size ever seen.  The packed weights stay shared in the builder."""
+    if key in cache:
+        cache[key] = cache.pop(key)          # most recently used last
+        return cache[key][0]
+    while len(cache) >= PLAN_CACHE_SIZE:
+        cache.pop(next(iter(cache)))
+    with builder.persist_scope() as owned:
+        plan = make()
+    cache[key] = (plan, owned)
+    return plan
 
 
 # ---- cond stage (frido/modules/encoders/modules.py:85-114) ---------------------------------------------
@@ -275,10 +294,8 @@ class BERTEmbedder(_Versioned, nn.Module):
         if self._rt is None:
             require_gpu(dev)
             self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev))
-        key = (B, n)
-        if key not in self._plans:
-            self._plans[key] = BertPlan(self._rt, B=B, n=n, dim=self.n_embed, depth=self.n_layer, vocab=self.vocab_size)
-        plan = self._plans[key]
+        plan = _cached_plan(self._plans, (B, n), self._rt, lambda: BertPlan(self._rt, B=B, n=n, dim=self.n_embed, depth=self.n_layer,
+                                                                            vocab=self.vocab_size))
         plan.tokens.copy_(tokens.reshape(-1))
         plan.prog.run(current_stream_ptr(dev))
         z = plan.out.view(B, n, self.n_embed).clone()
@@ -372,11 +389,8 @@ class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
         if self._rt is None:
             require_gpu(dev)
             self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev))
-        key = (B, n)
-        if key not in self._plans:
-            self._plans[key] = ClipTextPlan(self._rt, B=B, n=n, width=width, layers=layers, heads=heads, vocab=vocab,
-                                            embed_dim=embed_dim, normalize=self.normalize)
-        plan = self._plans[key]
+        plan = _cached_plan(self._plans, (B, n), self._rt, lambda: ClipTextPlan(self._rt, B=B, n=n, width=width, layers=layers, heads=heads,
+                                                                                vocab=vocab, embed_dim=embed_dim, normalize=self.normalize))
         plan.tokens.copy_(tokens.reshape(-1))
         plan.eot_rows.copy_(tokens.argmax(dim=-1) + torch.arange(B, device=dev) * n)      # clip/model.py: the EOT token has the highest id
         plan.prog.run(current_stream_ptr(dev))
@@ -396,16 +410,22 @@ class LitEma(nn.Module):
         self.m_name2s_name = {}
         self.register_buffer("decay", torch.tensor(decay, dtype=torch.float32))
         self.register_buffer("num_updates", torch.tensor(0 if use_num_upates else -1, dtype=torch.int))
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
         for name, p in model.named_parameters():
-            s_name = name.replace(".", "")
-            self.m_name2s_name[name] = s_name
-            self.register_buffer(s_name, p.clone().detach().data)
+            if p.requires_grad:              # ema.py:16-20: frozen parameters have no shadow (and no `model_ema.*` checkpoint key)
+                s_name = name.replace(".", "")
+                self.m_name2s_name[name] = s_name
+                self.register_buffer(s_name, p.clone().detach().data)
         self.collected_params = []
 
     def copy_to(self, model):
         shadow = dict(self.named_buffers())
         for key, p in model.named_parameters():
-            p.data.copy_(shadow[self.m_name2s_name[key]].data)
+            if p.requires_grad:
+                p.data.copy_(shadow[self.m_name2s_name[key]].data)
+            else:
+                assert key not in self.m_name2s_name
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters]

@@ -40,8 +40,11 @@ def all_gather_images(local, total=None, group=None):
 
 @torch.no_grad()
 def sample_images(model, cond, *, S, eta=1.0, sampler="ddim", scale=1.0, uncond=None, seed=0, sample0=0, noise="philox",
-                  num_stage=None, gather=True, total=None, log_every_t=10 ** 9):
-    """cond: this rank's conditioning shard [b, nctx, cd] on the GPU.  Returns decoded images (gathered)."""
+                  num_stage=None, gather=True, total=None, log_every_t=10 ** 9, gather_dtype="float32"):
+    """cond: this rank's conditioning shard [b, nctx, cd] on the GPU.  Returns decoded images (gathered).
+    gather_dtype "float32": (N, 3, H, W) f32 in [-1, 1] (what decode_first_stage returns; 25 MB / rank at 32 images);
+    "uint8" / "uint8_pil": the (N, H, W, 3) uint8 images of scripts/sample_diffusion.py custom_to_np (:115-121) / custom_to_pil
+    (:103-113), produced by the decoder's last epilogue -- the one all-gather then moves 6.3 MB / rank."""
     from .samplers import DDIMSampler, PLMSSampler
     unet = model.model.diffusion_model
     cls = PLMSSampler if sampler == "plms" else DDIMSampler
@@ -50,5 +53,10 @@ def sample_images(model, cond, *, S, eta=1.0, sampler="ddim", scale=1.0, uncond=
     z, _ = cls(model).sample(S=S, batch_size=b, shape=shape, conditioning=cond, num_stage=num_stage or unet.num_stage,
                              eta=eta, verbose=False, unconditional_guidance_scale=scale, unconditional_conditioning=uncond,
                              noise=noise, seed=seed, sample0=sample0, log_every_t=log_every_t)
-    img = model.decode_first_stage(z)
+    if gather_dtype == "float32":
+        img = model.decode_first_stage(z)
+    elif gather_dtype in ("uint8", "uint8_pil"):
+        img = model.decode_first_stage(z, to_uint8="pil" if gather_dtype == "uint8_pil" else "np")
+    else:
+        raise ValueError(f"gather_dtype {gather_dtype!r}: 'float32', 'uint8' or 'uint8_pil'")
     return all_gather_images(img, total=total) if gather else img

@@ -21,26 +21,6 @@ def _weights_of(module, device):
     return {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in module.state_dict().items()}
 
 
-def _timing_filter(ops):
-    """FRIDO_DEBUG_SKIP=KIND[,KIND...] (e.g. GN_APPLY,LAYERNORM, or GEMM:conv / GEMM:dense) drops those ops from the captured
-    step body.  TIMING EXPERIMENTS ONLY (the results are garbage): it measures what a bucket of launches costs inside the
-    replayed graph, which per-op event timing overstates (tools/ab_flags.sh FRIDO_DEBUG_SKIP "" GN_APPLY ...)."""
-    import os
-    skip = [k for k in os.environ.get("FRIDO_DEBUG_SKIP", "").split(",") if k]
-    if not skip:
-        return ops
-    names = {v: k[len("FRIDO_OP_"):] for k, v in _lib.OP_KINDS.items()}
-    out = []
-    for kind, st in ops:
-        n = names[kind]
-        tags = {n}
-        if n == "GEMM":
-            tags.add("GEMM:conv" if st.conv else "GEMM:dense")
-        if not tags & set(skip):
-            out.append((kind, st))
-    return out
-
-
 def _run1(builder, kind, stream, **kw):
     """Launch a single op immediately."""
     from .engine import Prog
@@ -288,7 +268,7 @@ class SamplerEngine:
             key = ("ddim", s)
             if key not in self.graphs:
                 full = Prog(self.dev, self.b.nsplit)
-                full.ops = _timing_filter(list(plan.step.ops))
+                full.ops = list(plan.step.ops)
                 full.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0))
                 full.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
                 full.keep = [plan]
@@ -353,19 +333,23 @@ class DecoderRuntime:
         self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
         self.plans = {}
 
+    U8_MODES = {False: 0, None: 0, True: 1, "np": 1, "pil": 2}
+
     def decode(self, z, inv_scale=None, return_code=False, to_uint8=False, force_codes=None):
         """z (B, Ctot, h, w) NCHW latent -> image (B, 3, H, W); inv_scale: per-scale multiplier (1/scale_factor).
-        to_uint8: return the (B, H, W, 3) uint8 array of scripts/sample_diffusion.py:115-121 instead (4x smaller to
-        gather / write)."""
+        to_uint8: True / "np" -> the (B, H, W, 3) uint8 array of scripts/sample_diffusion.py:115-121 (custom_to_np), "pil" -> the
+        pixel bytes of :103-113 (custom_to_pil's truncating conversion), written by the LAST conv's epilogue (r04: no f32
+        image, 4x less to gather / write)."""
         B, Ct, h, w = z.shape
         embed = self.cfg["embed_dim"]
         inv = tuple(float(v) for v in (inv_scale if inv_scale is not None else [1.0] * len(embed)))
-        key = (B, h, w, inv, force_codes is not None)
+        u8 = self.U8_MODES[to_uint8]
+        key = (B, h, w, inv, force_codes is not None, u8)
         st = current_stream_ptr(self.device)
         if key not in self.plans:
             z_state = torch.zeros(B, h * w, Ct, dtype=torch.float32, device=self.device)
             self.plans[key] = (z_state, VQDecodePlan(self.b, self.cfg["ddconfig"], embed, self.cfg["n_embed"], B=B, h=h, w=w,
-                                                      z_state=z_state, inv_scale=inv, forced=force_codes is not None))
+                                                      z_state=z_state, inv_scale=inv, forced=force_codes is not None, u8_mode=u8))
         z_state, plan = self.plans[key]
         if force_codes is not None:      # test hook: decode the given per-scale code maps instead of the argmin's
             for dst, src in zip(plan.force_idx, force_codes):
@@ -374,10 +358,9 @@ class DecoderRuntime:
         _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=zc.data_ptr(), dst=z_state.data_ptr(), B=B, HW=h * w, Csrc=Ct, c0=0,
               Cuse=Ct, Cdst=Ct, d0=0, to_nchw=0)
         plan.prog.run(st)
-        if to_uint8:
-            u8 = torch.empty(B, plan.H, plan.W, plan.a.out_ch, dtype=torch.uint8, device=self.device)
-            _run1(self.b, "FRIDO_OP_TO_U8", st, src=plan.out_nhwc.data_ptr(), dst=u8.data_ptr(), n=u8.numel())
-            return (u8, [i.view(B, -1) for i in plan.idx]) if return_code else u8
+        if u8:
+            img = plan.out_u8.view(B, plan.H, plan.W, plan.a.out_ch).clone()
+            return (img, [i.view(B, -1) for i in plan.idx]) if return_code else img
         out = torch.empty(B, plan.a.out_ch, plan.H, plan.W, dtype=torch.float32, device=self.device)
         _run1(self.b, "FRIDO_OP_RELAYOUT", st, src=plan.out_nhwc.data_ptr(), dst=out.data_ptr(), B=B, HW=plan.H * plan.W,
               Csrc=plan.a.out_ch, c0=0, Cuse=plan.a.out_ch, Cdst=plan.a.out_ch, d0=0, to_nchw=1)

@@ -109,7 +109,7 @@ def decoder_body(b, B, dd, prefix, z_op, h, w, out):
 
 
 class VQDecodePlan:
-    def __init__(self, b: Builder, ddconfig, embed_dim, n_embed, *, B, h, w, z_state, inv_scale, forced=False):
+    def __init__(self, b: Builder, ddconfig, embed_dim, n_embed, *, B, h, w, z_state, inv_scale, forced=False, u8_mode=0):
         """z_state: device f32 [B][h*w][sum(embed_dim)] NHWC latent (already in diffusion scale);
         inv_scale[i] multiplies scale i before quantisation."""
         self.b = b
@@ -120,7 +120,10 @@ class VQDecodePlan:
         hw = h * w
         up_levels = sum(1 for blk in a.body if blk.kind == "up")
         self.H, self.W = h << up_levels, w << up_levels
-        self.out_nhwc = torch.zeros(B * self.H * self.W, a.out_ch, dtype=torch.float32, device=dev)
+        # u8_mode 1 / 2: conv_out's epilogue writes the uint8 HWC image of scripts/sample_diffusion.py:103-121 (custom_to_np /
+        # custom_to_pil) instead of the f32 plane -- no f32 image tensor exists in that plan at all
+        self.out_u8 = torch.zeros(B * self.H * self.W, a.out_ch, dtype=torch.uint8, device=dev) if u8_mode else None
+        self.out_nhwc = None if u8_mode else torch.zeros(B * self.H * self.W, a.out_ch, dtype=torch.float32, device=dev)
         self.idx = [torch.zeros(B * hw, dtype=torch.int64, device=dev) for _ in embed_dim]
         self.quant = torch.zeros(B * hw, Ct, dtype=torch.float32, device=dev)
         self.force_idx = [torch.zeros(B * hw, dtype=torch.int64, device=dev) for _ in embed_dim] if forced else None
@@ -138,7 +141,7 @@ class VQDecodePlan:
         q_op.free()
         z_op = b.pack(pq.ptr, 1, B * hw, pq.C, 0, pq.C)
         pq.free()
-        decoder_body(b, B, ddconfig, "decoder", z_op, h, w, ("f32", _T(self.out_nhwc)))
+        decoder_body(b, B, ddconfig, "decoder", z_op, h, w, ("u8", self.out_u8, u8_mode) if u8_mode else ("f32", _T(self.out_nhwc)))
         z_op.free()
 
 

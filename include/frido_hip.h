@@ -14,8 +14,11 @@
  *     the 16-bit storage type).  One-plane mode (nsplit == 1): bf16.  Two-plane mode (nsplit == 2,
  *     the "bf16x3" precision keyword): a second plane holding the rounding residual lives `lo`
  *     elements after the first, products are accumulated as hi*hi + hi*lo + lo*hi in fp32 on the
- *     MFMA pipe; both planes are fp16 (frido_x3_plane_format() == 1: ≈2^-22 relative error) or,
- *     in a -DFRIDO_X3_F16=0 build, bf16 (≈2^-17).
+ *     MFMA pipe; both planes are fp16 (frido_x3_plane_format() == 1) or, in a -DFRIDO_X3_F16=0 build, bf16 (≈2^-17
+ *     relative, fp32's range).  fp16 pairs: representation error max(2^-22 |v|, 2^-25) -- relative down to |v| = 2^-3, an
+ *     absolute floor below (the lo plane is an fp16 subnormal there); values beyond +-65504 SATURATE at that bound when a
+ *     kernel of this library (or frido_amd.engine.pack_matrix) produces the operand -- a host packing operands itself must
+ *     clamp the same way, an inf plane makes the three-pass product NaN.
  */
 #ifndef FRIDO_HIP_H
 #define FRIDO_HIP_H
@@ -28,6 +31,14 @@ extern "C" {
 
 typedef void* frido_stream_t;   /* a hipStream_t */
 typedef uint16_t frido_bf16;
+
+/* Bumped on every incompatible change of a descriptor struct, a workspace layout or an operand element format; a host
+ * compiled against another value must not call into the library (frido_abi_version() returns the library's).
+ * 1: rounds 1-2.  2: FridoGemm.sk_mode / gn_part inserted mid-struct, FridoAttnSmall / FridoSoftmax / FridoGnStats grew, the
+ * split-K workspace starts with a 64-KiB ticket header that the CALLER zeroes once (frido_gemm_workspace_bytes), two-plane
+ * operands became fp16 pairs (frido_x3_plane_format() == 1).  3 (r04): FridoGemm grew at its END (out_u8 / ldu8 / u8_mode, the fused
+ * GroupNorm-apply input gn_*), two-plane operand producers saturate at +-65504. */
+#define FRIDO_ABI_VERSION 3
 
 #define FRIDO_OK 0
 #define FRIDO_EINVAL (-1)
@@ -112,6 +123,13 @@ typedef struct FridoGemm {
                                    epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
                                    streamlined epilogues (bit 5 / 6: only the split-K / GEGLU one); TIMING EXPERIMENTS ONLY
                                    (results are garbage): bit 2 = skip the whole epilogue, bit 3 = skip only its stores */
+    /* optional uint8 image output (r04: the output path of scripts/sample_diffusion.py fused into the decoder's last conv --
+       the all-gather and the NPZ / PNG writers then move uint8): out_u8[row * ldu8 + n] for n < N, NHWC.  u8_mode 1 =
+       custom_to_np (sample_diffusion.py:115-121): ((x + 1) * 127.5) clamped to [0, 255], truncated; 2 = custom_to_pil
+       (:103-113): x clamped to [-1, 1], (x + 1) / 2, times 255, truncated -- every step a separate fp32 rounding, like the
+       torch / numpy expressions.  x is the value the f32 output would hold; out_f32 / out_op may be null.  Element-wise epilogue
+       (no split-K, no GroupNorm partial sums). */
+    uint8_t* out_u8; int32_t ldu8, u8_mode;
 } FridoGemm;
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two
@@ -329,7 +347,7 @@ typedef struct FridoOp {
         FridoSoftmax softmax; FridoGeglu geglu; FridoPack pack; FridoRelayout relayout; FridoVq vq;
         FridoSamplerStep sampler_step; FridoHandoff handoff; FridoRandn randn; FridoStepAdd step_add;
         FridoFill fill; FridoTimeEmb time_emb; FridoConvT convt; FridoPlace place; FridoEmbed embed; FridoToU8 to_u8; FridoAttnSmall attn_small; FridoCopy copy; FridoSync sync; FridoL2Norm l2norm;
-        char _size[384];
+        char _size[512];
     } u;
 } FridoOp;
 

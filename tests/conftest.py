@@ -12,3 +12,9 @@ sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU check")
+
+# The GPU suite runs on the tiles the BENCHMARK runs on: the committed, library-hash-keyed tile cache (profiles/tune_cache.json,
+# written by `bench.py --retune`) is read-only here, so a GEMM signature the benchmark uses gets the benchmark's tile in every
+# test process (signatures the cache does not hold are tuned live, per process, and not written back).
+os.environ.setdefault("FRIDO_TUNE_CACHE", os.path.join(REPO, "profiles", "tune_cache.json"))
+os.environ.setdefault("FRIDO_TUNE_CACHE_READONLY", "1")

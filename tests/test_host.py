@@ -44,7 +44,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     assert len(declared) >= 25
     for name in declared:
         assert hasattr(L, name), f"libfrido_hip.so lacks {name} (declared in include/frido_hip.h)"
-    assert L.frido_abi_version() == 1
+    assert L.frido_abi_version() == _lib.ABI_VERSION >= 2       # bumped with every incompatible descriptor / workspace / plane-format change
     assert L.frido_sizeof_op() == C.sizeof(_lib.FridoOp)
     for kname, sname in _lib.KIND_STRUCT.items():
         assert L.frido_sizeof_desc(_lib.OP_KINDS[kname]) == C.sizeof(_lib.STRUCTS[sname]), sname
@@ -267,3 +267,22 @@ def test_every_shipped_yaml_model_tree_instantiates():
         assert isinstance(u, PyUNetModel) and isinstance(m.first_stage_model, VQModelInterface), name
         assert u.num_stage == len(m.split_embed_dim_list if hasattr(m, "split_embed_dim_list") else [0]) or u.num_stage >= 1
         assert hasattr(m.cond_stage_model, "encode"), name
+
+
+def test_lit_ema_shadows_only_trainable_parameters():
+    """ema.py:16-20: a parameter with requires_grad == False has no shadow buffer (and no `model_ema.*` checkpoint key);
+    copy_to leaves it alone."""
+    import torch.nn as nn
+    from frido_amd.models import LitEma
+    m = nn.Sequential(nn.Linear(3, 3), nn.Linear(3, 2))
+    for p in m[1].parameters():
+        p.requires_grad = False
+    ema = LitEma(m)
+    assert set(ema.m_name2s_name) == {"0.weight", "0.bias"}
+    assert {n for n, _ in ema.named_buffers()} == {"decay", "num_updates", "0weight", "0bias"}
+    frozen = m[1].weight.clone()
+    getattr(ema, "0weight").fill_(7.0)
+    ema.copy_to(m)
+    assert float(m[0].weight.mean()) == 7.0 and torch.equal(m[1].weight, frozen)
+    with pytest.raises(ValueError):
+        LitEma(m, decay=1.5)

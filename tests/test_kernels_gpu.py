@@ -824,3 +824,40 @@ def test_executor_side_stream_branches_join_correctly(monkeypatch):
         g.launch(st.cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(o0.view(), o1.view()) and torch.equal(p0.view(), p1.view())
+
+
+def test_two_plane_operands_saturate_instead_of_nan_and_keep_small_values():
+    """r04 (advisor): the fp16 hi / lo planes of the parity mode.  (a) |v| > 65504 used to become an inf hi plane and a -inf lo
+    plane, i.e. a NaN product; split_op now clamps, so the GEMM sees +-65504 -- finite, equal to the product with the clamped
+    operand.  (b) small magnitudes: the pair's error is max(2^-22 |v|, 2^-25) (include/frido_hip.h), an absolute floor below
+    |v| = 2^-3 -- operands scaled to 1e-5 still multiply to ~1e-3 relative (the floor), not to garbage."""
+    from frido_amd.engine import plane_dtype
+    if plane_dtype(2) != torch.float16:
+        pytest.skip("bf16-pair build: fp32's range, nothing saturates")
+    M, N, K = 64, 48, 64
+    a, w = _t("sat:a", M, K), _t("sat:w", N, K) / np.sqrt(K)
+    big = a.clone()
+    big[::7, ::5] *= 1e5                                    # up to ~3e5: beyond fp16
+    b = _builder(2, {"w.weight": w.cuda()})
+    bd = big.cuda()
+    a_op = b.pack(bd.data_ptr(), 1, M, K, 0, K)
+    out = b.linear(a_op, "w", bias=False)
+    _run(b)
+    got = out.view().cpu()
+    assert torch.isfinite(got).all()
+    ref = big.clamp(-65504.0, 65504.0) @ w.t()
+    assert _relerr(got, ref) < 2e-5
+    assert torch.isfinite(a_op.to_f32()).all() and float(a_op.to_f32().abs().max()) == 65504.0
+    # host packer (weights): same saturation
+    from frido_amd.engine import pack_matrix
+    wp = pack_matrix((w * 1e7).cuda(), 2)
+    assert torch.isfinite(wp.to_f32()).all() and float(wp.to_f32().abs().max()) == 65504.0
+    # small magnitudes: absolute floor 2^-25 per element
+    small = (a * 1e-5).cuda()
+    b2 = _builder(2, {"w.weight": w.cuda()})
+    s_op = b2.pack(small.data_ptr(), 1, M, K, 0, K)
+    err = (s_op.to_f32().cpu() - a * 1e-5).abs().max()
+    assert float(err) <= 2.0 ** -25 * 1.01
+    out2 = b2.linear(s_op, "w", bias=False)
+    _run(b2)
+    assert _relerr(out2.view().cpu(), (a * 1e-5) @ w.t()) < 5e-3

@@ -114,7 +114,7 @@ def test_vq_decode_matches_reference_golden():
     code = np.asarray(code)
     flips = (code != g["code"]).mean()
     print(f"vq_small: VQ code flips {flips:.2e}")
-    assert flips < 2e-3
+    assert flips == 0, "index work is bit-exact: the committed codes of the reference must come back (vq_small.code)"
     # the decoder itself, UNCONDITIONALLY: forced onto the reference's own codes (no VQ decision boundary in the comparison)
     forced = m.decode(h, force_codes=[g["code"][i] for i in range(len(VQ_SMALL["embed_dim"]))])
     r = _rel(forced, g["dec"])
@@ -151,15 +151,60 @@ def test_vq_encode_three_scales_matches_oracle():
     assert enc.shape == ref.shape and float((err > 5e-4 * float(ref.abs().max())).float().mean()) < 0.03
 
 
+def _to_np_u8(x):
+    """scripts/sample_diffusion.py:115-121 custom_to_np, evaluated with torch on the CPU exactly as the script does."""
+    return ((x.detach().cpu() + 1) * 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def _to_pil_u8(x):
+    """scripts/sample_diffusion.py:103-113 custom_to_pil per image: clamp, (x + 1) / 2, numpy's 255 * x, astype(uint8)."""
+    out = []
+    for xi in x.detach().cpu():
+        xi = (torch.clamp(xi, -1., 1.) + 1.) / 2.
+        out.append(torch.from_numpy((255 * xi.permute(1, 2, 0).numpy()).astype(np.uint8)))
+    return torch.stack(out)
+
+
 def test_uint8_output_path():
-    """scripts/sample_diffusion.py:115-121 custom_to_np, fused after the decoder."""
+    """the uint8 HWC image comes out of the decoder's LAST conv epilogue (no f32 image, no separate pass), in both
+    of the sampling script's conversions.  (a) bit-exact against the two formulas applied to this decoder's own f32 output --
+    the conversion itself; (b) against the formulas applied to the ORACLE's decode of the same codes: the only admissible
+    differences are pixels whose f32 value sits within the decoder's 1e-4 parity bound of a truncation boundary (off by one)."""
+    from oracle.vqgan import vq_decode
     g = golden("vq_small")
     m = _vq(VQ_SMALL)
     h = torch.from_numpy(g["h"]).cuda()
-    f = m.decode(h)
-    u8 = m.decode(h, to_uint8=True)
-    ref = ((f + 1) * 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
-    assert u8.dtype == torch.uint8 and u8.shape == ref.shape and torch.equal(u8, ref)
+    f, code = m.decode(h, return_code=True)
+    assert (np.asarray(code) != g["code"]).sum() == 0
+    u_np, u_pil = m.decode(h, to_uint8=True), m.decode(h, to_uint8="pil")
+    assert u_np.dtype == torch.uint8 and u_np.shape == (f.shape[0], f.shape[2], f.shape[3], 3) and u_np.is_contiguous()
+    assert torch.equal(u_np.cpu(), _to_np_u8(f)) and torch.equal(u_pil.cpu(), _to_pil_u8(f))
+    assert torch.equal(m.decode(h, to_uint8="np"), u_np)
+    assert not torch.equal(u_np, u_pil)                      # 127.5 (x + 1) and 255 ((x + 1) / 2) truncate differently
+    ref = vq_decode(synth_sd(vq_holder(VQ_SMALL), "first_stage_model."), VQ_SMALL, torch.from_numpy(g["h"]))
+    for got, want, scale in ((u_np, _to_np_u8(ref), 127.5), (u_pil, _to_pil_u8(ref), 127.5)):
+        diff = (got.cpu().int() - want.int()).abs()
+        assert int(diff.max()) <= 1
+        # a differing byte must be explained by a truncation boundary within the f32 parity bound of the oracle's value
+        y = ((ref.clamp(-1, 1) + 1) * scale).permute(0, 2, 3, 1)
+        near = (y - y.round()).abs() < 1e-4 * scale * 2
+        assert bool(near[diff > 0].all()) and float((diff > 0).float().mean()) < 1e-3
+
+
+def test_sample_images_uint8_gather_matches_float_path():
+    """pipeline.sample_images(gather_dtype='uint8' / 'uint8_pil'): same sampler run, image bytes from the decoder's epilogue."""
+    from frido_amd.pipeline import sample_images
+    gs = golden("sampler_small")
+    model = _frido(UNET_SMALL, VQ_SMALL)
+    c = torch.from_numpy(gs["c"]).cuda()
+    kw = dict(S=4, eta=1.0, seed=5, noise="philox")
+    f = sample_images(model, c, **kw)
+    u = sample_images(model, c, gather_dtype="uint8", **kw)
+    p = sample_images(model, c, gather_dtype="uint8_pil", **kw)
+    assert u.dtype == torch.uint8 and u.shape == (2, 64, 64, 3)
+    assert torch.equal(u.cpu(), _to_np_u8(f)) and torch.equal(p.cpu(), _to_pil_u8(f))
+    with pytest.raises(ValueError):
+        sample_images(model, c, gather_dtype="int8", **kw)
 
 
 def test_vq_full_width_decode_matches_reference_golden():
@@ -169,7 +214,7 @@ def test_vq_full_width_decode_matches_reference_golden():
     dec, code = m.decode(h, return_code=True)
     flips = (np.asarray(code) != g["code"]).mean()
     print(f"vq_full: VQ code flips {flips:.2e}")
-    assert flips < 1e-3
+    assert flips == 0, "index work is bit-exact: the committed codes of the reference must come back (vq_full.code)"
     ss = int(g["subsample"])
     forced = m.decode(h, force_codes=[g["code"][0], g["code"][1]])      # the 662-GFLOP conv path + 4 attention blocks, always compared
     r = _rel(forced[:, :, ::ss, ::ss], g["dec"])
@@ -650,9 +695,10 @@ def test_config1_full_width_end_to_end(run, S, precision):
 
 # bounds of the parity arithmetic end to end (r03: fp16 hi + fp16 lo operand planes), = measured value x ~10: latent rel 2.4e-6 - 5.8e-6
 # (the fp32 oracle itself: 1.7e-6 - 2.1e-6), 0 flipped VQ codes in every run, decoded pixels <= 8.3e-6 max-abs end to end and
-# 6 - 8e-6 for the decoder alone (profiles/r03_e2e_error.json).  The north star asks <= 1e-3.  A flipped code is still tolerated at a rate
-# (a decision boundary is a discontinuity: the fp32 oracle is not immune in principle), but the pixel bound applies whenever none flips.
-E2E_X3 = dict(latent_rel=5e-5, vq_flip_rate=5e-4, pix_max=1e-4)
+# 6 - 8e-6 for the decoder alone (profiles/r03_e2e_error.json).  The north star asks <= 1e-3.
+# r04: with the GPU suite pinned to the benchmark's tiles (tests/conftest.py) the committed fixtures must decode to EXACTLY the reference's codes:
+# `vq_flip_rate` is an exclusive bound on flips / codes, so 1e-9 admits none (one flip of 8192 already breaks the north star's 1e-3).
+E2E_X3 = dict(latent_rel=5e-5, vq_flip_rate=1e-9, pix_max=1e-4)
 # bounds of the bf16 (benchmark) arithmetic end to end, = measured value x ~2 (see DESIGN.md §5 for the measurements)
 # r02 measurements (gpurun_out/t_r02a.log): latent rel 0.85-1.2e-2, VQ flips 0.8-1.6 %, pixel error p50 1.4-2.1e-2 /
 # p99 0.21-0.28, decoder alone on identical codes 2.9-3.4e-2 max-abs
@@ -717,7 +763,7 @@ def test_config5_three_scale_512_forward_and_decode():
     ss = int(gv["dec_img_ss"])
     r = _rel(forced[:, :, ::ss, ::ss], gv["dec_img"])
     print(f"config5 decode: VQ flips {flips:.2e}, decoder rel err on the reference's codes {r:.2e}")
-    assert dec.shape == (1, 3, 512, 512) and flips < 1e-3 and r < 3e-4
+    assert dec.shape == (1, 3, 512, 512) and flips == 0 and r < 3e-4
     assert abs(float(forced.double().sum()) - float(gv["dec_img_sum"])) < 2e-4 * float(gv["dec_img_abs_sum"])
 
 
@@ -845,3 +891,69 @@ def test_sampling_inside_ema_scope_uses_the_ema_weights():
     z_train, _ = DDIMSampler(model).sample(noise=_Tape(tape), **kw)
     assert _rel(z_ema, ref(sd_ema)) < 1e-3 and _rel(z_train, ref(sd_train)) < 1e-3
     assert _rel(z_ema, z_train.cpu()) > 1e-2            # the two weight sets really differ
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: parity AT THE BATCH THE BENCHMARK RUNS.  M = B * HW selects the tiles (256 x 192 / 128 x 192 eight-wave at B = 16): the
+# full-width goldens above run at B = 1 or 2, so these tests drive the benchmarked tiles (pinned: tests/conftest.py) end to end.
+def _bench_ctx(B):
+    from frido_amd.synth import seeded_normal
+    return torch.from_numpy(seeded_normal("bench:ctx", (B, 26, 640)))
+
+
+@pytest.mark.parametrize("B,S,rows", [(16, 50, (0, 7, 15)), (32, 20, (0, 31))], ids=["config2_B16", "config4_shard_B32"])
+def test_benchmarked_batch_rows_equal_single_sample_runs(B, S, rows):
+    """BASELINE config 2 (B = 16) and config 4's per-GPU shard (B = 32) at full width: the Philox noise is keyed by the GLOBAL sample
+    index, so row i of the batched run must reproduce the B = 1 run with sample0 = i -- whose arithmetic the B = 1 goldens pin to
+    the reference -- to the parity bound: latent <= 5e-5, ZERO code flips, decoded pixels <= 1e-4 (north star: 1e-3)."""
+    from frido.models.diffusion.ddim import DDIMSampler
+    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3")
+    ctx = _bench_ctx(B).cuda()
+    kw = dict(S=S, shape=(6, 64, 64), num_stage=2, eta=1.0, verbose=False, noise="philox", seed=1004, log_every_t=10 ** 9)
+    zb, _ = DDIMSampler(model).sample(batch_size=B, conditioning=ctx, **kw)
+    ib, cb = model.decode_first_stage(zb, return_code=True)
+    cb = np.asarray(cb)                                    # [scale][B][HW]
+    assert torch.isfinite(zb).all() and torch.isfinite(ib).all() and float(zb.std()) > 0.1
+    worst = dict(latent=0.0, pix=0.0, flips=0)
+    for i in rows:
+        z1, _ = DDIMSampler(model).sample(batch_size=1, conditioning=ctx[i:i + 1].contiguous(), sample0=i, **kw)
+        i1, c1 = model.decode_first_stage(z1, return_code=True)
+        worst["latent"] = max(worst["latent"], _rel(zb[i:i + 1], z1.cpu()))
+        worst["flips"] += int((np.asarray(c1)[:, 0] != cb[:, i]).sum())
+        worst["pix"] = max(worst["pix"], float((ib[i:i + 1] - i1).abs().max()))
+    print(f"B = {B} vs B = 1 rows {rows}: {worst}")
+    _record(f"batch{B}/rows_vs_b1/ddim{S}", worst)
+    assert worst["latent"] < E2E_X3["latent_rel"] and worst["flips"] == 0 and worst["pix"] < E2E_X3["pix_max"]
+
+
+@pytest.mark.parametrize("B", [16, 32])
+def test_benchmarked_batch_forward_matches_oracle(B):
+    """One denoiser forward per stage at full width and the benchmark's batch against the oracle (the CPU restatement pinned
+    bit-exact to the reference): the 64^2 / 32^2 convolutions run on the tiles of the headline number here."""
+    from oracle.unet import unet_forward
+    from frido_amd.synth import seeded_normal
+    m = _unet(UNET_FULL)
+    sd = synth_sd(unet_holder(UNET_FULL), "model.diffusion_model.")
+    x = torch.from_numpy(seeded_normal("bench:x", (B, 6, 64, 64)))
+    ctx = _bench_ctx(B)
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(B)])
+    keep = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        for s in ((0, 1) if B == 16 else (1,)):
+            xin = x[:, :3 * (s + 1)].contiguous()
+            ref = unet_forward(sd, UNET_FULL, xin, t, ctx, s)
+            got = m(xin.cuda(), t.cuda(), context=ctx.cuda(), stage=s)
+            r = _rel(got, ref)
+            print(f"B = {B} full-width forward stage {s}: rel err {r:.2e}")
+            assert got.shape == ref.shape and r < 2e-4, (B, s)
+    finally:
+        torch.set_num_threads(keep)
+
+
+def test_decode_ignores_force_not_quantize_like_the_reference():
+    """msvqgan.py:376-399 accepts force_not_quantize and never reads it: same output with and without."""
+    g = golden("vq_small")
+    m = _vq(VQ_SMALL)
+    h = torch.from_numpy(g["h"]).cuda()
+    assert torch.equal(m.decode(h), m.decode(h, force_not_quantize=True))
