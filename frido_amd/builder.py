@@ -24,6 +24,9 @@ ATTN_FLASH_MIN_KEYS = int(os.environ.get("FRIDO_ATTN_FLASH_MIN_KEYS", "512"))
 # SHORT key sequences (cross-attention: 26 / 92 / 1 tokens) on planes with at least this many queries per sample also take the
 # flash kernel (one 32-key tile, no cross-wave score exchange) instead of the 16-query short-key kernel; 0 = never
 ATTN_FLASH_SHORT_NQ = int(os.environ.get("FRIDO_ATTN_FLASH_SHORT_NQ", "0"))
+# GroupNorm-apply fused into the 3x3 conv that consumes it (csrc/convgn.inc, two-plane mode, 64^2 / 32^2 planes): "1" = where the
+# launch fills the chip (>= 224 workgroups), "0" = never (gn_apply + ring conv: the r03 path), "force" = wherever the kernel applies
+GN_CONV = os.environ.get("FRIDO_GN_CONV", "1")
 
 
 class Builder:
@@ -367,6 +370,63 @@ class Builder:
         if res is not None and getattr(res, "gn_part", None) is not None and not self.prog.ops[-1][1].gn_part:
             self.pool.release(res.gn_part)
             res.gn_part = None
+
+    def gn_conv_tile(self, x1, x2, B, H, W, co, raw=None):
+        """FridoGemm tile (20: 256-row, 21: 128-row tiles) of the fused GroupNorm + 3x3 conv kernel for this plane, or 0 when the
+        launch does not qualify / would not fill the chip (the caller then emits groupnorm() + conv())."""
+        if GN_CONV == "0" or self.nsplit != 2 or self.device.type != "cuda":
+            return 0
+        tensors = [x1] + ([x2] if x2 is not None else []) + [r for r in (raw or ()) if r is not None]
+        if any(getattr(t, "bf16", False) or t.C % 32 for t in tensors):
+            return 0
+        C = x1.C + (x2.C if x2 is not None else 0)
+        if C > 960 or C % 32 or co % 192 or W not in (16, 32, 64) or (H * W) % 128:
+            return 0
+        M = B * H * W
+        for tile, bm, slots in ((20, 256, 396), (21, 128, 204)):
+            if (H * W) % bm or bm % W or (bm // W + 2) * (W + 2) > slots:
+                continue
+            if GN_CONV == "force" or (M // bm) * (co // 192) >= 224:
+                return tile
+        return 0
+
+    def gn_conv(self, tile, x1, x2, B, H, W, norm_w, eps, conv_w, *, gamma=None, beta=None, act=ACT_SILU, rowvec=None, residual=None,
+                skip=None):
+        """out = conv3x3(act(GroupNorm32(cat(x1, x2)) [* (1 + gamma) + beta])) [+ conv1x1_skip(cat(raw1, raw2))] + bias [+ rowvec]
+        [+ residual] in ONE launch after the GroupNorm statistics (pyunet.py:262-300; taming model.py:117-137): the normalised
+        operand is produced inside the conv kernel, gn_apply and its 8 B / element round trip do not exist.
+        norm_w: parameter prefix of the norm (weight / bias), conv_w: of the conv; skip = (raw1, raw2 or None, skip conv prefix)."""
+        HW, M = H * W, B * H * W
+        C = x1.C + (x2.C if x2 is not None else 0)
+        part, S = self.gn_stats(x1, x2, B, HW)
+        if skip is not None:
+            raw1, raw2, skip_w = skip
+            wop, cp, k2, bsum = self.conv_plus_skip_weight(conv_w, skip_w)
+            rawC = raw1.C + (raw2.C if raw2 is not None else 0)
+            assert cp == C and k2 == rawC, (cp, C, k2, rawC)
+            bias_ptr, ldb = bsum.data_ptr(), 9 * cp + k2
+        else:
+            wop, cp = self.conv_weight(conv_w + ".weight")
+            assert cp == C, (cp, C)
+            k2, bias_ptr, ldb = 0, self.bias(conv_w + ".bias"), 9 * cp
+        co = self.w[conv_w + ".weight"].shape[0]
+        gn = dict(gn_x1=x1.ptr, gn_C1=x1.C, gn_x2=x2.ptr if x2 is not None else None, gn_C2=x2.C if x2 is not None else 0,
+                  gn_partials=part.data_ptr(), gn_nsplit_px=S, gn_groups=32, gn_eps=eps, gn_weight=self.bias(norm_w + ".weight"),
+                  gn_bias=self.bias(norm_w + ".bias"), gn_gamma=gamma.ptr if gamma is not None else None,
+                  gn_beta=beta.ptr if beta is not None else None, gn_act=act)
+        if skip is not None:
+            gn.update(raw_x1=raw1.ptr, raw_C1=raw1.C, raw_x2=raw2.ptr if raw2 is not None else None, raw_C2=raw2.C if raw2 is not None else 0)
+        geom = dict(Hs=H, Ws=W, Cin=cp, Hl=H, Wl=W, Ho=H, Wo=W, kh=3, kw=3, stride=1, pad=1, up_shift=0, dn_shift=0)
+        res = self.f32(M, co)
+        kw = {}
+        if residual is not None:
+            kw.update(residual=residual.ptr, ldr=residual.C)
+        if rowvec is not None:
+            kw.update(rowvec=rowvec["ptr"], rows_per_vec=rowvec["rows_per_vec"], ldv=rowvec["ld"], rowvec_step=rowvec.get("step"))
+        self.prog.gemm(M, co, 9 * cp, None, wop, ldb=ldb, conv=geom, bias=bias_ptr, out_f32=res.ptr, ldo=co, K2=k2, tile=tile, gn=gn,
+                       gn_part=self._parts_for(res, M, co, rowvec=rowvec, residual=residual), **kw)
+        self.pool.release(part)
+        return res
 
     def gn_stats(self, x1, x2, B, HW):
         p1, p2 = getattr(x1, "gn_part", None), getattr(x2, "gn_part", None) if x2 is not None else None

@@ -1920,8 +1920,18 @@ int launch_patch(const FridoGemm& d, int nw, hipStream_t s) {
     return frido_check_launch("conv3x3_patch");
 }
 
+#include "convgn.inc"
+
 template <int NS, bool CONV>
 int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
+    if constexpr (NS == 2 && CONV) {
+        if (tile == 20) return launch_convgn(d, 256, s);
+        if (tile == 21) return launch_convgn(d, 128, s);
+    }
+    if (d.gn_x1) {
+        frido_set_error("igemm: a descriptor with a fused GroupNorm input (gn_x1) runs on tile 20 or 21 only");
+        return FRIDO_EINVAL;
+    }
     switch (tile) {
         case 1: return launch<128, 128, NS, CONV, 32>(d, s);
         case 2: return launch<128, 192, NS, CONV, 32>(d, s);
@@ -1995,6 +2005,10 @@ int frido_igemm_init() {
         frido_set_error("igemm: cannot set dynamic LDS size of the patch kernel");
         rc |= 1;
     }
+    if (convgn_init()) {
+        frido_set_error("igemm: cannot set dynamic LDS size of the fused GroupNorm + conv kernel");
+        rc |= 1;
+    }
     return rc ? FRIDO_EHIP : FRIDO_OK;
 }
 
@@ -2024,9 +2038,10 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     const FridoGemm& d = *dp;
     FRIDO_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, "empty problem");
     FRIDO_REQUIRE((d.K & 31) == 0 && (d.K2 & 63) == 0, "K must be a multiple of 32, K2 of 64 (zero-pad the operands)");
-    FRIDO_REQUIRE(d.K2 == 0 || (d.A2 && (d.lda2 & 7) == 0 && (d.K & 63) == 0 && d.batch == 1), "bad second A operand");
+    FRIDO_REQUIRE(d.K2 == 0 || (((d.A2 && (d.lda2 & 7) == 0) || (d.gn_x1 && d.raw_x1)) && (d.K & 63) == 0 && d.batch == 1), "bad second A operand");
     FRIDO_REQUIRE(d.nsplit == 1 || d.nsplit == 2, "nsplit must be 1 or 2");
-    FRIDO_REQUIRE(d.A && d.B, "null operand");
+    FRIDO_REQUIRE((d.A || d.gn_x1) && d.B, "null operand");
+    FRIDO_REQUIRE(!d.gn_x1 || d.tile == 20 || d.tile == 21, "a fused GroupNorm input (gn_x1) needs tile 20 or 21");
     FRIDO_REQUIRE(d.out_f32 || d.out_op || d.out_u8, "no output");
     FRIDO_REQUIRE(!d.out_u8 || ((d.u8_mode == 1 || d.u8_mode == 2) && d.ldu8 >= d.N && d.splitk <= 1 && !d.gn_part && !d.geglu && !d.up2_phase &&
                                 d.batch == 1),

@@ -234,9 +234,10 @@ class Prog:
              bias=None, rowvec=None, rows_per_vec=0, ldv=0, rowvec_step=None, alpha=1.0, act=0,
              residual=None, res_bs=0, ldr=0, out_f32=None, of_bs=0, ldo=0, out_op=None, oo_bs=0, ldoo=0,
              oo_lo=0, tile=0, conv=None, row_bias=None, geglu=0, res_bf16=0, out_bf16=0, batch_inner=0, a_bs2=0, b_bs2=0, of_bs2=0, oo_bs2=0, A2=None, lda2=0, K2=0,
-             gn_part=None, out_u8=None, ldu8=0, u8_mode=0):
-        """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples."""
-        ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else A
+             gn_part=None, out_u8=None, ldu8=0, u8_mode=0, gn=None):
+        """A/B: objects with .ptr/.lo (Operand / POperand) or (ptr, lo) tuples.  gn: the gn_* / raw_* fields of a fused GroupNorm +
+        conv launch (FridoGemm tiles 20 / 21: A is then None, the operand is produced in the kernel)."""
+        ap, alo = (A.ptr, A.lo) if hasattr(A, "ptr") else (A if A is not None else (None, 0))
         bp, blo = (B.ptr, B.lo) if hasattr(B, "ptr") else B
         kw = dict(M=M, N=N, K=K, batch=batch, nsplit=self.nsplit, A=ap, a_lo=alo if a_lo is None else a_lo,
                   a_bs=a_bs, lda=lda if lda is not None else K, B=bp, b_lo=blo if b_lo is None else b_lo,
@@ -265,6 +266,10 @@ class Prog:
             kw["gn_part"] = gn_part
         if out_u8 is not None:
             kw.update(out_u8=out_u8, ldu8=ldu8, u8_mode=u8_mode)
+        if gn is not None:
+            kw.update(gn)
+            if K2:
+                kw["K2"] = K2
         self.emit("FRIDO_OP_GEMM", **kw)
         if not tile and self.device.type == "cuda":
             from . import tune

@@ -198,15 +198,43 @@ class UNetStagePlan:
             d["step"] = self.step_ptr
         return d
 
+    def _norm_params(self, name):
+        """(parameter prefix, gamma, beta) of a GroupNorm32 / SPADE site (pyunet.py:209,233; spade_norm.py:44-60)."""
+        if self.a.use_spade:
+            g, be = self.spade.get(name, (None, None))
+            return name + ".param_free_norm", g, be
+        return name, None, None
+
     def _res_block(self, blk, x1, x2, h, w, ridx):
         """pyunet.py:262-300.  x1 (+x2 = skip tensor, virtual concat).  Returns F32 [Bx*h*w][cout]."""
         b, HW = self.b, h * w
         pre = blk.prefix
         has_skip = (pre + ".skip_connection.weight") in b.w
-        a1, raw = self._norm(x1, x2, HW, pre + ".in_layers.0", 1e-5, ACT_SILU, want_raw=has_skip)
         rv = self._rowvec(ridx)
         if rv["rows_per_vec"] is None:
             rv["rows_per_vec"] = HW
+        # r04: on the 64^2 / 32^2 planes both GroupNorm-apply passes ride inside the convs that consume them (csrc/convgn.inc)
+        n1, g1, be1 = self._norm_params(pre + ".in_layers.0")
+        n2, g2, be2 = self._norm_params(pre + ".out_layers.0")
+        bf16_maps = any(getattr(m, "bf16", False) for m in (g1, g2) if m is not None)
+        t1 = 0 if bf16_maps else b.gn_conv_tile(x1, x2, self.Bx, h, w, blk.cout)
+        if t1 and has_skip:
+            Craw = x1.C + (x2.C if x2 is not None else 0)
+            if Craw % 64:
+                t1 = 0
+        if t1:
+            hmid = b.gn_conv(t1, x1, x2, self.Bx, h, w, n1, 1e-5, pre + ".in_layers.2", gamma=g1, beta=be1, rowvec=rv)
+            t2 = b.gn_conv_tile(hmid, None, self.Bx, h, w, blk.cout, raw=(x1, x2) if has_skip else None)
+            assert t2, "the second conv of a ResBlock sits on the same plane as the first"
+            if has_skip:
+                out = b.gn_conv(t2, hmid, None, self.Bx, h, w, n2, 1e-5, pre + ".out_layers.3", gamma=g2, beta=be2,
+                                skip=(x1, x2, pre + ".skip_connection"))
+            else:
+                assert x2 is None
+                out = b.gn_conv(t2, hmid, None, self.Bx, h, w, n2, 1e-5, pre + ".out_layers.3", gamma=g2, beta=be2, residual=x1)
+            hmid.free()
+            return out
+        a1, raw = self._norm(x1, x2, HW, pre + ".in_layers.0", 1e-5, ACT_SILU, want_raw=has_skip)
         hmid = b.conv(a1, self.Bx, h, w, pre + ".in_layers.2", rowvec=rv)
         a1.free()
         a2, _ = self._norm(hmid, None, HW, pre + ".out_layers.0", 1e-5, ACT_SILU)

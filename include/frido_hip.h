@@ -118,7 +118,8 @@ typedef struct FridoGemm {
     int32_t tile;               /* 0 auto, 1 = 128x128, 2 = 128x192, 3 = 64x64, 4 = 128x64, 5 = 64x192, 6 = 64x128 (BK 32);
                                    7 = 256x128 (8 waves), 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64), 17 = 256x128 with BK 64;
-                                   18 = 128x192 on eight waves, 19 = 256x192 on eight waves (bf16x3 mode) */
+                                   18 = 128x192 on eight waves, 19 = 256x192 on eight waves (bf16x3 mode);
+                                   20 = 256x192 / 21 = 128x192 with the GroupNorm-apply fused in (gn_* below, bf16x3 mode) */
     int32_t flags;              /* A/B switches (0 = defaults): bit 0 = do not stage the bf16 residual tile through LDS in the
                                    epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
                                    streamlined epilogues (bit 5 / 6: only the split-K / GEGLU one); TIMING EXPERIMENTS ONLY
@@ -130,6 +131,21 @@ typedef struct FridoGemm {
        torch / numpy expressions.  x is the value the f32 output would hold; out_f32 / out_op may be null.  Element-wise epilogue
        (no split-K, no GroupNorm partial sums). */
     uint8_t* out_u8; int32_t ldu8, u8_mode;
+    /* optional FUSED GroupNorm-apply input (r04; tiles 20 / 21, conv mode 3x3 stride 1 pad 1 on 16..64-pixel-wide planes, nsplit 2):
+       the A operand is not read from memory (A may be null) but produced inside the kernel from the f32 residual stream --
+           a = act( (x - mean) * rstd * gn_weight[c] + gn_bias[c]  [* (1 + gn_gamma) + gn_beta] )
+       i.e. frido_gn_apply (pyunet.py:262-300 in_layers / out_layers; spade_norm.py:44-60) folded into the convolution that
+       consumes it: x = the virtual channel concat of gn_x1 [rows][gn_C1] and gn_x2 [rows][gn_C2] (gn_C1 + gn_C2 == Cin,
+       multiples of 32), gn_partials = frido_gn_stats' output [Bimg][gn_nsplit_px][gn_groups][2] doubles, gn_gamma / gn_beta
+       optional f32 maps [rows][Cin], gn_act = FRIDO_ACT_NONE / FRIDO_ACT_SILU.  Per-element arithmetic is frido_gn_apply's.
+       With K2 > 0 the appended K range reads the RAW f32 rows raw_x1 [rows][raw_C1] | raw_x2 [rows][raw_C2]
+       (raw_C1 + raw_C2 == K2), split into hi / lo planes in the kernel, instead of the operand A2 (the fused 1x1 skip conv).
+       M and H*W multiples of the tile's 256 / 128 rows, N a multiple of 192, no split-K. */
+    const float* gn_x1; const float* gn_x2; int32_t gn_C1, gn_C2;
+    const double* gn_partials; int32_t gn_nsplit_px, gn_groups; float gn_eps;
+    const float* gn_weight; const float* gn_bias; const float* gn_gamma; const float* gn_beta;
+    int32_t gn_act;
+    const float* raw_x1; const float* raw_x2; int32_t raw_C1, raw_C2;
 } FridoGemm;
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two

@@ -856,8 +856,131 @@ def test_two_plane_operands_saturate_instead_of_nan_and_keep_small_values():
     small = (a * 1e-5).cuda()
     b2 = _builder(2, {"w.weight": w.cuda()})
     s_op = b2.pack(small.data_ptr(), 1, M, K, 0, K)
-    err = (s_op.to_f32().cpu() - a * 1e-5).abs().max()
-    assert float(err) <= 2.0 ** -25 * 1.01
     out2 = b2.linear(s_op, "w", bias=False)
     _run(b2)
+    err = (s_op.to_f32().cpu() - a * 1e-5).abs().max()
+    assert float(err) <= 2.0 ** -25 * 1.01
     assert _relerr(out2.view().cpu(), (a * 1e-5) @ w.t()) < 5e-3
+
+
+# W, tile, C1, C2, Cout, B, SPADE, skip (appended raw 1x1 conv), residual, input from a producing conv's partial sums
+GN_CONV_CASES = [
+    (64, 20, 192, 0, 192, 1, False, False, True, False),
+    (64, 20, 384, 192, 192, 1, True, True, False, False),       # concat input + SPADE + fused skip conv (the 64^2 output blocks)
+    (32, 21, 384, 0, 384, 2, False, False, True, True),         # statistics from the producer's epilogue partial sums
+    (32, 21, 576, 384, 384, 1, True, True, False, False),       # 960 channels: the table's limit
+    (32, 20, 192, 0, 192, 2, True, False, False, False),        # 256-row tiles on a 32-wide plane (8 image rows per tile)
+    (16, 21, 64, 64, 192, 2, False, True, False, False),        # 16-wide plane, 128-row tiles
+    (64, 20, 32, 0, 192, 1, False, False, False, False),        # a single chunk: no staging overlap at all
+    (32, 21, 64, 0, 192, 1, False, True, False, False),         # two chunks + one raw chunk
+]
+
+
+@pytest.mark.parametrize("case", GN_CONV_CASES)
+def test_gn_conv_fused(case):
+    """csrc/convgn.inc: GroupNorm(32) [+ SPADE] + SiLU applied INSIDE the 3x3 conv that consumes it (+ the 1x1 skip conv of the raw
+    input as an appended K range, + bias / timestep vector / residual in the epilogue), against F.group_norm -> F.silu -> F.conv2d in
+    fp32 -- and against the two-kernel path (gn_apply + ring conv) it replaces, whose operand bits it reproduces."""
+    from frido_amd.builder import ACT_SILU
+    W, tile, C1, C2, Cout, B, spade, skip, resid, from_parts = case
+    H, C = W, C1 + C2
+    HW, M = H * W, B * H * W
+    Cr = 128 if skip else 0
+    x1 = _t("fc:x1", B, HW, C1) * 1.5 + 0.3
+    x2 = _t("fc:x2", B, HW, C2) * 0.7 if C2 else None
+    w, bi = 1 + 0.1 * _t("fc:gw", C), 0.1 * _t("fc:gb", C)
+    gam, bet = (0.3 * _t("fc:gg", B, HW, C), 0.3 * _t("fc:gbt", B, HW, C)) if spade else (None, None)
+    wc, bc = _t("fc:wc", Cout, C, 3, 3) / np.sqrt(9 * C), _t("fc:bc", Cout)
+    ws, bs = (_t("fc:ws", Cout, Cr, 1, 1) / np.sqrt(Cr), _t("fc:bs", Cout)) if skip else (None, None)
+    raw = _t("fc:raw", B, HW, Cr) if skip else None
+    res = _t("fc:res", M, Cout) if resid else None
+    tvec = _t("fc:tv", 3, Cout)                       # timestep table: row 1 is selected by the device step counter
+    weights = {"n.weight": w.cuda(), "n.bias": bi.cuda(), "c.weight": wc.cuda(), "c.bias": bc.cuda()}
+    if skip:
+        weights.update({"s.weight": ws.cuda(), "s.bias": bs.cuda()})
+    Cp = 64
+    if from_parts:
+        weights.update({"p.weight": (_t("fc:pw", C1, Cp, 3, 3) / np.sqrt(9 * Cp)).cuda(), "p.bias": _t("fc:pb", C1).cuda()})
+    b = _builder(2, weights)
+    if from_parts:      # x1 = output of a conv of this library: carries per-channel partial sums (FridoGemm.gn_part)
+        from frido_amd import tune
+        xin = _t("fc:pin", B, Cp, H, W)
+        xd = xin.cuda()
+        a_in = b.pack(xd.data_ptr(), B, HW, Cp, 0, Cp, nchw=True)
+        was = tune.ENABLED
+        tune.ENABLED = False
+        f1 = b.conv(a_in, B, H, W, "p")
+        tune.ENABLED = was
+        assert f1.gn_part is not None
+        x1 = F.conv2d(xin, weights["p.weight"].cpu(), weights["p.bias"].cpu(), padding=1).permute(0, 2, 3, 1).reshape(B, HW, C1)
+    else:
+        f1 = b.f32(M, C1)
+        f1.view().copy_(x1.view(M, C1).cuda())
+    f2 = None
+    if C2:
+        f2 = b.f32(M, C2)
+        f2.view().copy_(x2.view(M, C2).cuda())
+    g = be = None
+    if spade:
+        g, be = b.f32(M, C), b.f32(M, C)
+        g.view().copy_(gam.view(M, C).cuda())
+        be.view().copy_(bet.view(M, C).cuda())
+    fr = None
+    if skip:
+        fr = b.f32(M, Cr)
+        fr.view().copy_(raw.view(M, Cr).cuda())
+    r = None
+    if resid:
+        r = b.f32(M, Cout)
+        r.view().copy_(res.cuda())
+    tv = tvec.cuda()
+    step = torch.tensor([1], dtype=torch.int32, device="cuda")
+    rv = dict(ptr=tv.data_ptr(), ld=Cout, rows_per_vec=1 << 30, step=step.data_ptr())
+    out = b.gn_conv(tile, f1, f2, B, H, W, "n", 1e-5, "c", gamma=g, beta=be, act=ACT_SILU, rowvec=rv, residual=r,
+                    skip=(fr, None, "s") if skip else None)
+    st = b.prog.ops[-1][1]
+    assert st.tile == tile and st.gn_x1 and not st.A
+    # the path it replaces, in the same program: gn_apply -> operand -> ring conv (+ skip as A2)
+    a_ref, raw_ref = b.groupnorm(f1, f2, B, HW, "n", 1e-5, gamma=g, beta=be, act=ACT_SILU, want_raw=False)
+    if skip:
+        raw_op = b.pack(fr.ptr, 1, M, Cr, 0, Cr)
+        out2 = b.conv_plus_skip(a_ref, raw_op, B, H, W, "c", "s")
+    else:
+        out2 = b.conv(a_ref, B, H, W, "c", residual=r, rowvec=rv)
+    _run(b)
+    xc = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    xn = xc.permute(0, 2, 1).reshape(B, C, H, W)
+    y = F.group_norm(xn, 32, w, bi, 1e-5)
+    if spade:
+        y = y * (1 + gam.permute(0, 2, 1).reshape(B, C, H, W)) + bet.permute(0, 2, 1).reshape(B, C, H, W)
+    ref = F.conv2d(F.silu(y), wc, bc, padding=1)
+    if skip:
+        ref = ref + F.conv2d(raw.permute(0, 2, 1).reshape(B, Cr, H, W), ws, bs)
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout) + tvec[1]
+    if resid:
+        ref = ref + res
+    got = out.view().cpu()
+    assert torch.isfinite(got).all()
+    assert _relerr(got, ref) < 2e-5, _relerr(got, ref)
+    if not skip:      # same operand bits, same products; only the fp32 accumulation order differs (chunk-major vs tap-major k walk)
+        assert _relerr(got, out2.view().cpu()) < 3e-6
+    # the epilogue's GroupNorm partial sums of THIS conv's output (the next norm's statistics)
+    if out.gn_part is not None:
+        parts = out.gn_part[: (M // 32) * Cout * 8].view(torch.float32).view(M // 32, Cout, 2).cpu().double()
+        blocks = got.double().view(M // 32, 32, Cout)
+        assert _relerr(parts[:, :, 0], blocks.sum(1)) < 1e-5 and _relerr(parts[:, :, 1], (blocks ** 2).sum(1)) < 1e-5
+
+
+def test_gn_conv_rejects_what_it_cannot_run():
+    import ctypes as C_
+    from frido_amd import _lib
+    kind, st = _lib.make_op("FRIDO_OP_GEMM", M=4096, N=192, K=9 * 64, batch=1, nsplit=2, conv=1, Hs=64, Ws=64, Cin=64, Hl=64, Wl=64,
+                            Ho=64, Wo=64, kh=3, kw=3, stride=1, pad=1, padx=1, ldb=9 * 64, tile=20, gn_C1=64, gn_groups=32)
+    dummy = torch.zeros(64, device="cuda")
+    st.B, st.out_f32, st.ldo = dummy.data_ptr(), dummy.data_ptr(), 192
+    assert _lib.lib().frido_gemm(C_.addressof(st), None) == -1            # no A and no gn_x1
+    st.gn_x1 = dummy.data_ptr()
+    assert _lib.lib().frido_gemm(C_.addressof(st), None) == -1            # gn_x1 without statistics / affine parameters
+    assert b"fused GroupNorm" in _lib.lib().frido_last_error()
+    st.tile = 7
+    assert _lib.lib().frido_gemm(C_.addressof(st), None) == -1            # a fused descriptor on a ring tile

@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Error-budget table of the bf16x3 mode: keep ONE bf16 plane of a single operand class inside the parity
-arithmetic and measure the end-to-end error against the reference's own CPU run (config 1: layout2i f8f4 full width, B = 1,
-DDIM-50, eta = 1, torch noise stream; tests/golden/sampler_full.npz).   python tools/x3_single_plane_table.py
-Each variant runs in its own process (the switches are read at import).  -> profiles/r03_x3_single_plane_table.txt"""
+"""Error-budget table of the two-plane (parity) mode: keep ONE 16-bit plane of a single operand class inside the parity arithmetic
+and measure the end-to-end error against the reference's own CPU run (config 1: layout2i f8f4 full width, B = 1, DDIM-50,
+eta = 1, torch noise stream; tests/golden/sampler_full.npz).   python tools/x3_single_plane_table.py
+Each variant runs in its own process (the switches are read at import).  r03 ran it with bf16-pair planes
+(profiles/r03_x3_single_plane_table.txt); r04 with the shipped FP16 planes, adding the rows the r03 verdict asks for: the
+cheapest 2-pass variant -- WEIGHTS in one fp16 plane (11 bits), activations hi + lo -- for all weights, the denoiser's only and
+the decoder's only, and the SPADE maps rounded to fp16 (profiles/r04_x3_single_plane_table.txt).  The experiment hooks live HERE
+(lo planes zeroed / maps rounded after the plans are built), not in the library: accuracy experiments, the timings mean nothing."""
 import json
 import os
 import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = [("bf16x3 everywhere (shipped)", {}, "bf16x3", "bf16x3"),
+VARIANTS = [("two planes everywhere (shipped)", {}, "bf16x3", "bf16x3"),
+            ("ALL weights in ONE fp16 plane (2 MFMA passes)", {"X3_EXP": "w_all"}, "bf16x3", "bf16x3"),
+            ("denoiser weights in one fp16 plane", {"X3_EXP": "w_unet"}, "bf16x3", "bf16x3"),
+            ("MS-VQGAN decoder weights in one fp16 plane", {"X3_EXP": "w_vq"}, "bf16x3", "bf16x3"),
+            ("SPADE gamma / beta maps rounded to fp16", {"X3_EXP": "spade_f16"}, "bf16x3", "bf16x3"),
+            ("cached cross-attention K / V^T: hi plane only", {"FRIDO_X3_CROSSKV_HI": "1"}, "bf16x3", "bf16x3"),
             ("MS-VQGAN decoder in bf16 (one plane)", {}, "bf16x3", "bf16"),
             ("SPADE gamma / beta maps stored as bf16", {"FRIDO_X3_SPADE_BF16": "1"}, "bf16x3", "bf16x3"),
-            ("cached cross-attention K / V^T: hi plane only", {"FRIDO_X3_CROSSKV_HI": "1"}, "bf16x3", "bf16x3"),
             ("bf16 everywhere (throughput mode)", {}, "bf16", "bf16")]
 
 CHILD = r'''
@@ -30,6 +38,41 @@ cfg["cond_stage_config"], cfg["conditioning_key"] = "__is_unconditional__", "cro
 m = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
 fill_module(m.model, "model."); fill_module(m.first_stage_model, "first_stage_model.")
 m.scale_factor.copy_(torch.tensor([0.9, 1.1])); m = m.cuda().eval()
+EXP = os.environ.get("X3_EXP", "")
+if EXP == "spade_f16":
+    from frido_amd import unet_plan
+    build0 = unet_plan.UNetStagePlan._build_pre
+    def build_pre(self):
+        prog = build0(self)
+        run0 = prog.run
+        def run(stream):
+            run0(stream)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                for g_, b_ in self.spade.values():
+                    g_.t.copy_(g_.t.half().float()); b_.t.copy_(b_.t.half().float())
+        prog.run = run
+        return prog
+    unet_plan.UNetStagePlan._build_pre = build_pre
+if EXP.startswith("w_"):
+    # build every plan first (a short run + a decode), then zero the residual plane of the packed WEIGHT operands
+    from frido_amd.engine import Operand
+    DDIMSampler(m).sample(S=50, batch_size=1, shape=(6, 64, 64), conditioning=torch.from_numpy(g["c"]).cuda(), num_stage=2, eta=1.0,
+                          verbose=False, noise="philox")
+    m.decode_first_stage(torch.zeros(1, 6, 64, 64, device="cuda"))
+    m.decode_first_stage(torch.zeros(1, 6, 64, 64, device="cuda"), force_codes=[np.zeros(4096, np.int64)] * 2, return_code=False)
+    def zero_lo(builder):
+        n = 0
+        for k, v in builder._wcache.items():
+            if k[0] == "vT":
+                continue
+            for o in (v if isinstance(v, tuple) else (v,)):
+                if isinstance(o, Operand) and o.nsplit == 2:
+                    o.t[1].zero_(); n += 1
+        return n
+    n = 0
+    if EXP in ("w_all", "w_unet"): n += zero_lo(m.model.diffusion_model.runtime().b)
+    if EXP in ("w_all", "w_vq"): n += zero_lo(m.first_stage_model.runtime().b)
+    print("zeroed the lo plane of", n, "weight operands", file=sys.stderr)
 rec = T._Rec(); torch.manual_seed(23)
 z, _ = DDIMSampler(m).sample(S=50, batch_size=1, shape=(6, 64, 64), conditioning=torch.from_numpy(g["c"]).cuda(), num_stage=2, eta=1.0,
                              verbose=False, log_every_t=int(g["ddim50_args"][3]), noise=rec)
