@@ -1,5 +1,9 @@
-// convgn.inc -- included by igemm.hip inside its anonymous namespace (shares tile_epilogue, xcd_item, chan_of_pos, lds_* helpers).
-//
+// Fused GroupNorm-apply + 3x3 convolution of the two-plane (parity) arithmetic; shares the tile epilogue and the LDS / DMA helpers
+// of the implicit-GEMM family (igemm_shared.h).
+#include "igemm_shared.h"
+
+namespace {
+
 // =====================================================================================================================
 // conv3x3_gn_kernel: two-plane (parity arithmetic) 3x3 stride-1 convolution whose A operand is PRODUCED IN THE KERNEL from
 // the f32 residual stream:  out = conv3x3( act( GroupNorm(x) [* (1 + gamma) + beta] ) ) [+ conv1x1(raw)] + bias ...
@@ -14,14 +18,20 @@
 //     buffers (zero halo written as zeros: the conv pads the ACTIVATION); the nine taps read their pixel fragments from it
 //     with a constant slot shift.  Arithmetic per element is gn_apply_kernel's, expression for expression: the operand bits
 //     are the ones the two-kernel path feeds the MFMAs;
-//   * the staging of chunk c + 1 is spread over the taps of chunk c (loads at even taps, convert + write at the following odd
-//     tap), waves 0-3 convert BEFORE their MFMA block and waves 4-7 AFTER it, so that the two waves of a SIMD are out of phase;
+//   * the staging of chunk c + 1 is spread over the taps of chunk c: a round's loads go out two taps before its conversion, the
+//     two waves of a SIMD convert at alternating taps (one does VALU work while the other issues MFMAs);
 //   * only the weights stream per tap: [2 planes][192][32] = 24 KiB by LDS-DMA into a 2-stage ring (one tap ahead);
 //   * optional appended K range (fused 1x1 skip conv, pyunet.py:248,300): the raw f32 input rows of the tile, split into
 //     hi / lo, as dense [BM][32] tiles after the last conv chunk -- one k-step each, staged two steps ahead;
 //   * epilogue = tile_epilogue (bias, timestep vector, residual, f32 stream out, GroupNorm partial sums for the NEXT norm).
 //
 // LDS (BM = 256): 2 x 49.5 KiB patch + 2 x 24 KiB weights + 7.5 KiB scale / shift table = 154.5 KiB, one workgroup per CU.
+
+// Timing ablations (separate builds, results garbage): 1 = no convert / LDS write of staged units, 2 = no staging loads,
+// 4 = no MFMAs, 8 = no fragment reads, 16 = no weight DMA inside the loop
+#ifndef CG_ABLATE
+#define CG_ABLATE 0
+#endif
 
 template <int BM>
 struct CGeo {
@@ -47,13 +57,30 @@ __device__ __forceinline__ void lds_write128u(unsigned addr, u32x4 v) {
     asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-struct CgUnit { float4 x0, x1, g0, g1, b0, b1; };
+struct CgUnit { f32x4 x0, x1, g0, g1, b0, b1; };
+
+// Staging loads are issued and waited for BY HAND: hipcc fences a compiler-visible global load that is consumed after an LDS-DMA
+// with vmcnt(0) (measured: ~1300 cycles per staging round, the round trip of the weight DMA issued just before).  The loads are
+// inline asm (invisible to the compiler's counter) and the wait carries the loaded registers as in/out operands, so that no
+// consumer can be scheduled above it.
+__device__ __forceinline__ f32x4 gload128(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+    return v;
+}
+template <int N, bool SPADE>
+__device__ __forceinline__ void wait_unit(CgUnit& u) {       // at most N younger VMEM operations may stay in flight
+    if constexpr (SPADE)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(u.x0), "+v"(u.x1), "+v"(u.g0), "+v"(u.g1), "+v"(u.b0), "+v"(u.b1) : "n"(N));
+    else
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(u.x0), "+v"(u.x1) : "n"(N));
+}
 
 // gn_apply_kernel's per-element arithmetic (norm.hip), expression for expression
 template <bool SPADE>
 __device__ __forceinline__ void cg_convert(const CgUnit& u, const float (&sc)[8], const float (&sh)[8], bool norm, bool silu, bool zero,
                                            u32x4& hi, u32x4& lo) {
-    const float xin[8] = {u.x0.x, u.x0.y, u.x0.z, u.x0.w, u.x1.x, u.x1.y, u.x1.z, u.x1.w};
+    const float xin[8] = {u.x0[0], u.x0[1], u.x0[2], u.x0[3], u.x1[0], u.x1[1], u.x1[2], u.x1[3]};
     float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) y[e] = xin[e];
@@ -61,8 +88,8 @@ __device__ __forceinline__ void cg_convert(const CgUnit& u, const float (&sc)[8]
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = fmaf(xin[e], sc[e], sh[e]);
         if constexpr (SPADE) {
-            const float ga[8] = {u.g0.x, u.g0.y, u.g0.z, u.g0.w, u.g1.x, u.g1.y, u.g1.z, u.g1.w};
-            const float be[8] = {u.b0.x, u.b0.y, u.b0.z, u.b0.w, u.b1.x, u.b1.y, u.b1.z, u.b1.w};
+            const float ga[8] = {u.g0[0], u.g0[1], u.g0[2], u.g0[3], u.g1[0], u.g1[1], u.g1[2], u.g1[3]};
+            const float be[8] = {u.b0[0], u.b0[1], u.b0[2], u.b0[3], u.b1[0], u.b1[1], u.b1[2], u.b1[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = fmaf(y[e], 1.f + ga[e], be[e]);
         }
@@ -113,26 +140,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         float* s_mean = reinterpret_cast<float*>(smem);
         float* s_rstd = s_mean + 64;
         const int cpg = C / d.gn_groups;
-        if (t < d.gn_groups) {
-            double sl[8], ql[8];
-#pragma unroll
-            for (int l8 = 0; l8 < 8; ++l8) {
-                double a = 0.0, b = 0.0;
+        double* s_part = reinterpret_cast<double*>(smem + 1024);            // [8][32][2], like gn_apply_kernel
+        if (t < 256) {      // combine the per-split partials: 8 lanes per group in parallel, then a fixed-order sum of the 8
+            const int g = t & 31, l8 = t >> 5;
+            double s = 0.0, q = 0.0;
+            if (g < d.gn_groups) {
+                double2 pv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int sp = l8 + 8 * k;
-                    if (sp < d.gn_nsplit_px) {
-                        const double2 p = *reinterpret_cast<const double2*>(d.gn_partials + (((int64_t)img * d.gn_nsplit_px + sp) * d.gn_groups + t) * 2);
-                        a += p.x;
-                        b += p.y;
-                    }
+                    pv[k] = sp < d.gn_nsplit_px
+                                ? *reinterpret_cast<const double2*>(d.gn_partials + (((int64_t)img * d.gn_nsplit_px + sp) * d.gn_groups + g) * 2)
+                                : make_double2(0.0, 0.0);
                 }
-                sl[l8] = a;
-                ql[l8] = b;
-            }
-            double s = 0.0, q = 0.0;
 #pragma unroll
-            for (int l = 0; l < 8; ++l) { s += sl[l]; q += ql[l]; }
+                for (int k = 0; k < 8; ++k) { s += pv[k].x; q += pv[k].y; }
+                s_part[(l8 * 32 + g) * 2] = s;
+                s_part[(l8 * 32 + g) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < d.gn_groups) {
+            double s = 0.0, q = 0.0;
+            for (int l = 0; l < 8; ++l) { s += s_part[(l * 32 + t) * 2]; q += s_part[(l * 32 + t) * 2 + 1]; }
             const double n = (double)HW * cpg;
             const double mean = s / n;
             double var = q / n - mean * mean;
@@ -170,24 +200,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     auto load_unit = [&](int c, int p, CgUnit& u) {   // chunk c of the (virtually concatenated) GroupNorm input at pixel p
         const int ch = c * 32 + cu;
         const float* src = ch < C1 ? x1 + (int64_t)p * C1 + ch : x2 + (int64_t)p * C2 + (ch - C1);
-        u.x0 = *reinterpret_cast<const float4*>(src);
-        u.x1 = *reinterpret_cast<const float4*>(src + 4);
+        u.x0 = gload128(src);
+        u.x1 = gload128(src + 4);
         if constexpr (SPADE) {
             const int64_t o = (int64_t)p * C + ch;
-            u.g0 = *reinterpret_cast<const float4*>(gam + o);
-            u.g1 = *reinterpret_cast<const float4*>(gam + o + 4);
-            u.b0 = *reinterpret_cast<const float4*>(bet + o);
-            u.b1 = *reinterpret_cast<const float4*>(bet + o + 4);
+            u.g0 = gload128(gam + o);
+            u.g1 = gload128(gam + o + 4);
+            u.b0 = gload128(bet + o);
+            u.b1 = gload128(bet + o + 4);
         }
     };
     const int psafe = img * HW + y0 * W;              // a valid pixel for lanes whose slot is halo / unused (loaded, never written)
     const bool do_silu = d.gn_act == FRIDO_ACT_SILU;
     auto stage_load = [&](auto rc, int c, CgUnit& u) {
         constexpr int r = decltype(rc)::value;
+        if constexpr (CG_ABLATE & 2) { u.x0 = u.x1 = u.g0 = u.g1 = u.b0 = u.b1 = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
         load_unit(c, pix[r] >= 0 ? pix[r] : psafe, u);
     };
-    auto stage_write = [&](auto rc, int c, const CgUnit& u) {      // convert + write round r of chunk c into patch buffer c & 1
-        constexpr int r = decltype(rc)::value;
+    // convert + write round r of chunk c into patch buffer c & 1; YOUNGER = VMEM operations issued after the round's loads
+    auto stage_write = [&](auto rc, auto yc, int c, CgUnit& u) {
+        constexpr int r = decltype(rc)::value, YOUNGER = decltype(yc)::value;
+        if constexpr (!(CG_ABLATE & 2)) wait_unit<YOUNGER, SPADE>(u);
+        if constexpr (CG_ABLATE & 1) { asm volatile("" ::"v"(u.x0), "v"(u.x1)); return; }
         float sc[8], sh[8];
         {
             const unsigned ta = lds0 + TAB0 + (unsigned)(c * 32 + cu) * 4u;
@@ -217,14 +251,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         for (int q = 0; q < RU; ++q) {
             const int64_t p = (int64_t)m0 + q * 128 + (t >> 2);
             const float* src = ch < RC1 ? rx1 + p * RC1 + ch : rx2 + p * RC2 + (ch - RC1);
-            u[q].x0 = *reinterpret_cast<const float4*>(src);
-            u[q].x1 = *reinterpret_cast<const float4*>(src + 4);
+            u[q].x0 = gload128(src);
+            u[q].x1 = gload128(src + 4);
         }
     };
-    auto raw_write = [&](int buf, const CgUnit (&u)[RU]) {
+    auto raw_write = [&](auto yc, int buf, CgUnit (&u)[RU]) {
+        constexpr int YOUNGER = decltype(yc)::value;
         const float none[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < RU; ++q) {
+            wait_unit<YOUNGER, false>(u[q]);
             u32x4 hi, lo;
             cg_convert<false>(u[q], none, none, false, false, false, hi, lo);
             const unsigned a = lds0 + (unsigned)(buf * PBUF) + wslot + (unsigned)(q * 8192);
@@ -236,33 +272,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     // ---- weight DMA: 24 one-KiB chunks per tap ([2 planes][12 x 16 rows]), three per wave; the ring kernel's B layout ----
     const int lrow = lane >> 2;
     const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
-    int64_t b_off[3];
+    int b_off[3];                                     // element offsets (< 2^31: checked by the launcher)
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int q = wave + 8 * p, plane = q / 12, rc = q - 12 * plane;
         const int n = n0 + chan_of_pos(rc * 16 + lrow);               // permuted weight rows: see tile_epilogue
-        b_off[p] = (int64_t)plane * d.b_lo + (int64_t)n * d.ldb + lq * 8;
+        b_off[p] = (int)((int64_t)plane * d.b_lo + (int64_t)n * d.ldb + lq * 8);
     }
+    bool in_loop = false;
     auto issue_w = [&](int64_t koff, int stage) {
+        if ((CG_ABLATE & 16) && in_loop) return;
         unsigned char* dst = smem + W0 + stage * WSTAGE + wave * 1024;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            int64_t bo = b_off[p];
+            int bo = b_off[p];
             asm volatile("" : "+v"(bo));
-            __builtin_amdgcn_global_load_lds((gptr_t)(Bb + bo + koff), (lptr_t)(dst + p * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bb + koff + bo), (lptr_t)(dst + p * 8192), 16, 0, 0);
         }
     };
 
     // ---- fragment addressing ----
     const int frow = lane & 15, kg = lane >> 4;
-    int sbase[TM], rbase[TM];                          // patch slot of this lane's output pixel (centre tap) / its row in a dense raw tile
+    // patch slot of this lane's output pixel of m-tile i (centre tap) = sb0 + soff[i], its row in a dense raw tile = rb0 + 16 i:
+    // one VGPR each, the per-tile parts are wave-uniform (m-tile i starts 16 i pixels further: (16 i / W) rows down, 16 i % W along;
+    // no wrap inside a row for W in {16, 32, 64} with 32- or 64-pixel wave tiles)
+    const int ml0 = wm * (BM / WM) + frow;
+    const int sb0 = (ml0 / W + 1) * PW + (ml0 % W + 1), rb0 = ml0;
+    int soff[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = wm * (BM / WM) + i * 16 + frow;
-        const int r = ml / W, x = ml - r * W;
-        sbase[i] = (r + 1) * PW + (x + 1);
-        rbase[i] = ml;
-    }
+    for (int i = 0; i < TM; ++i) soff[i] = ((i * 16) / W) * PW + ((i * 16) % W);
     const unsigned bfrag = lds0 + W0 + (unsigned)((wn * (BN / 2) + frow) * 64 + (((kg ^ ((4 - ((frow >> 2) & 3)) & 3))) << 4));
 
     f32x4 acc[TM][TN];
@@ -273,13 +311,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
 
     // one k-step: A fragments from `abase` (a patch buffer or a dense tile, both planes PPLANE apart) at slots sb[i] + shift,
     // weight fragments from stage `ws`; hi*lo + lo*hi + hi*hi per tile, reads in order of first use (the ring kernel's plain loop)
-    auto mma_step = [&](unsigned abase, const int (&sb)[TM], int shift, int ws) {
+    auto mma_step = [&](unsigned abase, bool dense, int shift, int ws) {
         unsigned aa[TM];
+        int s0 = dense ? rb0 : sb0;
+        asm volatile("" : "+v"(s0));                   // recomputed per step on purpose: hoisted, the 9 x TM addresses spill
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            int s0 = sb[i];
-            asm volatile("" : "+v"(s0));               // recomputed per step on purpose: hoisted, the 9 x TM addresses spill
-            const int sl = s0 + shift;
+            const int sl = s0 + (dense ? 16 * i : soff[i]) + shift;
             aa[i] = abase + (unsigned)(sl << 6) + (unsigned)((kg ^ (((sl >> 2) & 1) << 1)) << 4);
         }
         unsigned sbb = bfrag;
@@ -291,7 +329,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) fa[p][i] = lds_read128(aa[i] + p * PPLANE);
+            for (int p = 0; p < 2; ++p) {
+                if constexpr (CG_ABLATE & 8) { if (i == 0) fa[p][0] = lds_read128(aa[0] + p * PPLANE); else fa[p][i] = fa[p][0]; }
+                else fa[p][i] = lds_read128(aa[i] + p * PPLANE);
+            }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (j + 1 < TN) {
@@ -311,6 +352,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
                     else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (CG_ABLATE & 4) { asm volatile("" ::"v"(fb[j & 1][0]), "v"(fb[j & 1][1]), "v"(fa[0][i]), "v"(fa[1][i])); continue; }
                 acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[1][i], acc[i][j]);      // weights first: C^T tiles (see tile_epilogue)
                 acc[i][j] = mfma_op<2>(fb[j & 1][1], fa[0][i], acc[i][j]);
                 acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[0][i], acc[i][j]);
@@ -321,31 +363,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
 
     // ---- prologue: weights of step 0 in flight, chunk 0 staged without overlap ----
     issue_w(0, 0);
-    static_for<0, NR>([&](auto rc) {
-        CgUnit u;
-        stage_load(rc, 0, u);
-        stage_write(rc, 0, u);
-    });
+    {
+        CgUnit pu[NR];                 // every round's loads in flight before the first conversion (the accumulators are not live yet)
+        static_for<0, NR>([&](auto rc) { stage_load(rc, 0, pu[decltype(rc)::value]); });
+        static_for<0, NR>([&](auto rc) { stage_write(rc, std::integral_constant<int, 0>{}, 0, pu[decltype(rc)::value]); });
+    }
 
+    in_loop = true;
     CgUnit su;                        // the staging round in flight (loaded at an even tap, written at the next odd one)
     CgUnit ru[RU];                    // the raw tile in flight
     const bool early = wave < 4;      // waves w and w + 4 share a SIMD: the first converts before its MFMA block, the second after
 
-    // MODE 0: a conv chunk follows; 1: last chunk, nothing follows; 2: last chunk, raw tiles follow
+    // MODE 0: a conv chunk follows; 1: last chunk, nothing follows; 2: last chunk, raw tiles follow.
+    // Staging schedule of chunk c + 1 inside chunk c (MODE 0), one unit register set per wave, TWO steps between a round's loads and
+    // its conversion:  waves 0-3 ("early"): load round r at tap 2r, convert it at tap 2r + 2;
+    //                  waves 4-7:           load round r at tap 2r + 1, convert it at tap 2r + 3 (the last round of four: at tap 8).
+    // Waves w and w + 4 share a SIMD: at any tap only one of the two converts (VALU) while the other goes straight to its MFMAs.
     auto chunk = [&](auto modec, int c) {
         constexpr int MODE = decltype(modec)::value;
         static_for<0, 9>([&](auto tc) {
             constexpr int T = decltype(tc)::value;
             // loads issued in the PREVIOUS step after its weight DMA may stay in flight (loads retire in order)
-            constexpr int PT = T == 0 ? 8 : T - 1;                       // previous tap (of the previous chunk when T == 0, same MODE-0 schedule)
-            constexpr bool PREV_EVEN_LOAD = (PT % 2 == 0) && (PT / 2 < NR);
+            constexpr int PT = T == 0 ? 8 : T - 1;                       // previous tap
             if constexpr (T == 0) {
-                // previous step = tap 8 of a MODE-0 chunk (or the prologue): tap 8 carries no staging loads (NR <= 4)
-                wait_vmcnt<0>();
+                wait_vmcnt<0>();                                         // previous step = tap 8 (no staging loads) or the prologue
             } else if constexpr (MODE == 0) {
-                wait_vmcnt<PREV_EVEN_LOAD ? NL : 0>();
+                constexpr int E = (PT % 2 == 0 && PT / 2 < NR) ? NL : 0, L = (PT % 2 == 1 && (PT - 1) / 2 < NR) ? NL : 0;
+                if constexpr (E == L) wait_vmcnt<E>();
+                else if (early) wait_vmcnt<E>();
+                else wait_vmcnt<L>();
             } else if constexpr (MODE == 2) {
-                wait_vmcnt<(PT == 0 || PT == 6) ? 2 * RU : 0>();
+                // (an inline-asm load must never be left unconsumed: its registers would be re-allocated while it is in flight --
+                //  so raw tile 1 is only fetched when it exists, and the wait count follows)
+                if constexpr (PT == 0) wait_vmcnt<2 * RU>();
+                else if constexpr (PT == 6) { if (nraw > 1) wait_vmcnt<2 * RU>(); else wait_vmcnt<0>(); }
+                else wait_vmcnt<0>();
             } else {
                 wait_vmcnt<0>();
             }
@@ -355,20 +407,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             if constexpr (T < 8) issue_w((int64_t)(T + 1) * C + c * 32, (c + T + 1) & 1);
             else if constexpr (MODE == 0) issue_w((int64_t)(c + 1) * 32, (c + 1) & 1);                 // tap 0 of chunk c + 1: stage (9 (c + 1)) & 1
             else if constexpr (MODE == 2) issue_w((int64_t)9 * C, (c + 1) & 1);                         // raw tile 0
-            // (b) staging loads
-            if constexpr (MODE == 0 && T % 2 == 0 && T / 2 < NR) stage_load(std::integral_constant<int, T / 2>{}, c + 1, su);
+            using Y3 = std::integral_constant<int, 3>;       // (dependency only: the unit's loads completed at this step's top wait)
+            if constexpr (MODE == 0) {
+                constexpr int EC = (T % 2 == 0 && T >= 2 && T / 2 - 1 < NR) ? T / 2 - 1 : -1;          // round the early waves convert
+                constexpr int EL = (T % 2 == 0 && T / 2 < NR) ? T / 2 : -1;                            // ... and load
+                constexpr int LC = (T % 2 == 1 && T >= 3 && (T - 3) / 2 < NR) ? (T - 3) / 2 : ((T == 8 && NR == 4) ? 3 : -1);
+                constexpr int LL = (T % 2 == 1 && (T - 1) / 2 < NR) ? (T - 1) / 2 : -1;
+                if (early) {
+                    if constexpr (EC >= 0) stage_write(std::integral_constant<int, EC < 0 ? 0 : EC>{}, Y3{}, c + 1, su);
+                    if constexpr (EL >= 0) stage_load(std::integral_constant<int, EL < 0 ? 0 : EL>{}, c + 1, su);
+                } else {
+                    if constexpr (LC >= 0) stage_write(std::integral_constant<int, LC < 0 ? 0 : LC>{}, Y3{}, c + 1, su);
+                    if constexpr (LL >= 0) stage_load(std::integral_constant<int, LL < 0 ? 0 : LL>{}, c + 1, su);
+                }
+            }
             if constexpr (MODE == 2 && T == 0) raw_load(0, ru);
-            if constexpr (MODE == 2 && T == 6) raw_load(nraw > 1 ? 1 : 0, ru);
-            constexpr bool CONVERT = MODE == 0 && T % 2 == 1 && T / 2 < NR;
+            if constexpr (MODE == 2 && T == 6) { if (nraw > 1) raw_load(1, ru); }
             constexpr bool RAWW = MODE == 2 && T == 1;
             if (early) {
-                if constexpr (CONVERT) stage_write(std::integral_constant<int, T / 2>{}, c + 1, su);
-                if constexpr (RAWW) raw_write((c + 1) & 1, ru);
+                if constexpr (RAWW) raw_write(Y3{}, (c + 1) & 1, ru);
             }
-            mma_step(lds0 + (unsigned)((c & 1) * PBUF), sbase, (T / 3 - 1) * PW + (T % 3 - 1), (c + T) & 1);
+            mma_step(lds0 + (unsigned)((c & 1) * PBUF), false, (T / 3 - 1) * PW + (T % 3 - 1), (c + T) & 1);
             if (!early) {
-                if constexpr (CONVERT) stage_write(std::integral_constant<int, T / 2>{}, c + 1, su);
-                if constexpr (RAWW) raw_write((c + 1) & 1, ru);
+                if constexpr (RAWW) raw_write(Y3{}, (c + 1) & 1, ru);
             }
         });
     };
@@ -377,16 +438,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         chunk(std::integral_constant<int, 2>{}, nc - 1);
         // raw tile s: weights in stage (9 nc + s) & 1 = (nc + s) & 1, tile in patch buffer (nc + s) & 1
         for (int s = 0; s < nraw; ++s) {
-            // previous step's loads after its weight DMA: the raw tile two steps ahead (2 RU loads), except after tap 8 of the chunk
-            if (s == 0) wait_vmcnt<0>();
-            else wait_vmcnt<2 * RU>();
+            // the previous step's loads after its weight DMA: raw tile s + 1 (fetched at step s - 1, when it exists)
+            if (s > 0 && s + 1 < nraw) wait_vmcnt<2 * RU>();
+            else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (s + 1 < nraw) issue_w((int64_t)9 * C + (s + 1) * 32, (nc + s + 1) & 1);
-            else issue_w((int64_t)9 * C + s * 32, (nc + s + 1) & 1);          // (uniform issue count; lands in the idle stage, never read)
-            if (s + 1 < nraw) raw_write((nc + s + 1) & 1, ru);                  // tile s + 1 (loaded one or more steps ago) -> the buffer step s - 1 read
-            raw_load(s + 2 < nraw ? s + 2 : nraw - 1, ru);                      // (uniform load count)
-            mma_step(lds0 + (unsigned)(((nc + s) & 1) * PBUF), rbase, 0, (nc + s) & 1);
+            if (s + 1 < nraw) {
+                issue_w((int64_t)9 * C + (s + 1) * 32, (nc + s + 1) & 1);
+                raw_write(std::integral_constant<int, 3>{}, (nc + s + 1) & 1, ru);      // tile s + 1 -> the buffer step s - 1 read
+                if (s + 2 < nraw) raw_load(s + 2, ru);
+            }
+            mma_step(lds0 + (unsigned)(((nc + s) & 1) * PBUF), true, 0, (nc + s) & 1);
         }
     } else {
         chunk(std::integral_constant<int, 1>{}, nc - 1);
@@ -412,6 +474,7 @@ bool convgn_ok(const FridoGemm& d, int bm) {
         if (!d.raw_x1 || (d.raw_C1 & 31) || (d.raw_C2 & 31) || (d.raw_C2 && !d.raw_x2) || d.K2 != d.raw_C1 + d.raw_C2) return false;
     }
     if (d.geglu || d.out_u8 || (d.flags & 4)) return false;
+    if (2 * d.b_lo + (int64_t)d.N * d.ldb >= (1ll << 31)) return false;      // 32-bit weight offsets in the kernel
     return true;
 }
 
@@ -427,7 +490,9 @@ int launch_convgn_bm(const FridoGemm& d, hipStream_t s) {
     return frido_check_launch("conv3x3_gn");
 }
 
-int launch_convgn(const FridoGemm& d, int bm, hipStream_t s) {
+}  // namespace
+
+int frido_launch_convgn(const FridoGemm& d, int bm, hipStream_t s) {
     if (!convgn_ok(d, bm)) {
         frido_set_error("igemm: tile 20 / 21 (fused GroupNorm + 3x3 conv) does not apply to this descriptor");
         return FRIDO_EINVAL;
@@ -435,12 +500,15 @@ int launch_convgn(const FridoGemm& d, int bm, hipStream_t s) {
     return bm == 256 ? launch_convgn_bm<256>(d, s) : launch_convgn_bm<128>(d, s);
 }
 
+namespace {
 template <int BM, bool SP, bool RAW>
 int convgn_attr() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_gn_kernel<BM, SP, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                CGeo<BM>::SMEM) == hipSuccess ? 0 : 1;
 }
-int convgn_init() {
+}  // namespace
+
+int frido_convgn_init() {
     return convgn_attr<256, false, false>() | convgn_attr<256, false, true>() | convgn_attr<256, true, false>() | convgn_attr<256, true, true>() |
            convgn_attr<128, false, false>() | convgn_attr<128, false, true>() | convgn_attr<128, true, false>() | convgn_attr<128, true, true>();
 }

@@ -180,7 +180,7 @@ def test_uint8_output_path():
     assert u_np.dtype == torch.uint8 and u_np.shape == (f.shape[0], f.shape[2], f.shape[3], 3) and u_np.is_contiguous()
     assert torch.equal(u_np.cpu(), _to_np_u8(f)) and torch.equal(u_pil.cpu(), _to_pil_u8(f))
     assert torch.equal(m.decode(h, to_uint8="np"), u_np)
-    assert not torch.equal(u_np, u_pil)                      # 127.5 (x + 1) and 255 ((x + 1) / 2) truncate differently
+    # (127.5 (x + 1) and 255 ((x + 1) / 2) round differently in fp32 only on rare values: the two outputs usually coincide)
     ref = vq_decode(synth_sd(vq_holder(VQ_SMALL), "first_stage_model."), VQ_SMALL, torch.from_numpy(g["h"]))
     for got, want, scale in ((u_np, _to_np_u8(ref), 127.5), (u_pil, _to_pil_u8(ref), 127.5)):
         diff = (got.cpu().int() - want.int()).abs()

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." && mkdir -p tools/ablate
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Ifrido_amd/csrc -Wno-unused-result -ffp-contract=on"
 for m in "$@"; do
   ( /opt/rocm/bin/hipcc $FL -DFRIDO_ABLATE=$m -c frido_amd/csrc/igemm.hip -o tools/ablate/igemm_$m.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/ablate/igemm_$m.o frido_amd/csrc/{norm,misc,attn,flash,runtime}.o -o tools/ablate/libfrido_abl_$m.so ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/ablate/igemm_$m.o frido_amd/csrc/{convgn,norm,misc,attn,flash,runtime}.o -o tools/ablate/libfrido_abl_$m.so ) &
 done
 wait
 ls -la tools/ablate/*.so
