@@ -370,6 +370,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     }
 
     in_loop = true;
+#ifdef CG_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // (A/B) static priority for the second-dispatched half: MI355X_MICROARCH.md "Two waves per SIMD" item 4
+#endif
     CgUnit su;                        // the staging round in flight (loaded at an even tap, written at the next odd one)
     CgUnit ru[RU];                    // the raw tile in flight
     const bool early = wave < 4;      // waves w and w + 4 share a SIMD: the first converts before its MFMA block, the second after

@@ -357,9 +357,11 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 gbg[jo][e] = d.bias && n + 16 < d.N ? d.bias[n + 16] : 0.f;
             }
     }
-    if constexpr (NS == 1) {
-        // the fused GEGLU projection of the bf16 sampler: every LDS access in inline asm, one hand-counted lgkmcnt(0) per slab
-        // (hipcc fences C++ LDS reads of a kernel that issues LDS-DMA with vmcnt(0), which on CDNA4 also waits for STORES)
+    {
+        // the fused GEGLU projection of the sampler (r04: both arithmetic modes -- the two-plane mode ran the rolled generic loop
+        // below, whose epilogue cost twice its 12 k-steps of MFMAs on the 32^2 planes): every LDS access in inline asm, one
+        // hand-counted lgkmcnt(0) per slab (hipcc fences C++ LDS reads of a kernel that issues LDS-DMA with vmcnt(0), which on
+        // CDNA4 also waits for STORES).  (x + b) == fma(x, 1, b): the values are the generic loop's, bit for bit.
         if (d.geglu && d.out_op && d.alpha == 1.0f && !(d.flags & 80)) {
             constexpr int OC = WC / 2, LPRG = OC / 8, RPPG = 64 / LPRG < 16 ? 64 / LPRG : 16, NPG = (16 + RPPG - 1) / RPPG;
             const int gr = lane / LPRG, oc = (lane - gr * LPRG) * 8;          // row, first output column of this lane
@@ -391,8 +393,18 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                     const int m = m0 + wm * WR + i * 16 + r;
                     if (col_ok && r < 16 && m < d.M) {
                         const float4 a = lo[pp], b = hi[pp];
-                        *reinterpret_cast<uint4*>(d.out_op + (int64_t)m * d.ldoo + no) =
-                            make_uint4(pack2_bf16(a.x, a.y), pack2_bf16(a.z, a.w), pack2_bf16(b.x, b.y), pack2_bf16(b.z, b.w));
+                        if constexpr (NS == 1) {
+                            *reinterpret_cast<uint4*>(d.out_op + (int64_t)m * d.ldoo + no) =
+                                make_uint4(pack2_bf16(a.x, a.y), pack2_bf16(a.z, a.w), pack2_bf16(b.x, b.y), pack2_bf16(b.z, b.w));
+                        } else {
+                            const float ov[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                            uint32_t h[8], l[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) split_op(ov[e], NS, h[e], l[e]);
+                            frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + no;
+                            *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                            *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+                        }
                     }
                 });
             });
