@@ -27,6 +27,11 @@ ATTN_FLASH_SHORT_NQ = int(os.environ.get("FRIDO_ATTN_FLASH_SHORT_NQ", "0"))
 # GroupNorm-apply fused into the 3x3 conv that consumes it (csrc/convgn.inc, two-plane mode, 64^2 / 32^2 planes): "1" = where the
 # launch fills the chip (>= 224 workgroups), "0" = never (gn_apply + ring conv: the r03 path), "force" = wherever the kernel applies
 GN_CONV = os.environ.get("FRIDO_GN_CONV", "1")
+# fused kernel with K split over slices on the 16 x 16 planes (48 tiles): built, tested, measured -- a tie per launch (100 us vs 100.5 us for
+# gn_fused + the split-K ring conv) and -2.3 % end to end (profiles/r04_gnconv_splitk_ab.txt: few chunks per slice leave the prologue's
+# un-overlapped staging and the 196-KB partial-sum epilogue uncovered), so it stays OFF; the C ABI keeps the option (FridoGemm.splitk on tiles 20 / 21)
+GN_CONV_SPLITK = os.environ.get("FRIDO_GN_CONV_SPLITK", "0") != "0"
+GN_CONV_PREFER = int(os.environ.get("FRIDO_GN_CONV_PREFER", "256"))      # A/B: which tile height is tried first where both fill the chip
 
 
 class Builder:
@@ -372,26 +377,33 @@ class Builder:
             res.gn_part = None
 
     def gn_conv_tile(self, x1, x2, B, H, W, co, raw=None):
-        """FridoGemm tile (20: 256-row, 21: 128-row tiles) of the fused GroupNorm + 3x3 conv kernel for this plane, or 0 when the
-        launch does not qualify / would not fill the chip (the caller then emits groupnorm() + conv())."""
+        """(tile, splitk) of the fused GroupNorm + 3x3 conv kernel for this plane -- FridoGemm tile 20 (256-row tiles) or 21 (128-row),
+        K split over `splitk` slices where the tiles alone would leave the chip idle (16 x 16 planes) -- or (0, 1) when the launch
+        does not qualify / cannot fill the chip (the caller then emits groupnorm() + conv())."""
         if GN_CONV == "0" or self.nsplit != 2 or self.device.type != "cuda":
-            return 0
+            return 0, 1
         tensors = [x1] + ([x2] if x2 is not None else []) + [r for r in (raw or ()) if r is not None]
         if any(getattr(t, "bf16", False) or t.C % 32 for t in tensors):
-            return 0
+            return 0, 1
         C = x1.C + (x2.C if x2 is not None else 0)
         if C > 960 or C % 32 or co % 192 or W not in (16, 32, 64) or (H * W) % 128:
-            return 0
+            return 0, 1
         M = B * H * W
-        for tile, bm, slots in ((20, 256, 396), (21, 128, 204)):
-            if (H * W) % bm or bm % W or (bm // W + 2) * (W + 2) > slots:
-                continue
+        order = ((20, 256, 396), (21, 128, 204)) if GN_CONV_PREFER == 256 else ((21, 128, 204), (20, 256, 396))
+        fits = [(tile, bm) for tile, bm, slots in order if not ((H * W) % bm or bm % W or (bm // W + 2) * (W + 2) > slots)]
+        for tile, bm in fits:
             if GN_CONV == "force" or (M // bm) * (co // 192) >= 224:
-                return tile
-        return 0
+                return tile, 1
+        if GN_CONV_SPLITK:
+            for tile, bm in fits:       # split-K: ~256 workgroups, every slice at least two 32-channel chunks (18 k-steps)
+                tiles = (M // bm) * (co // 192)
+                sk = min(-(-256 // tiles), (C // 32) // 2, 8)
+                if sk >= 2 and tiles * sk >= 192:
+                    return tile, sk
+        return 0, 1
 
     def gn_conv(self, tile, x1, x2, B, H, W, norm_w, eps, conv_w, *, gamma=None, beta=None, act=ACT_SILU, rowvec=None, residual=None,
-                skip=None):
+                skip=None, splitk=1):
         """out = conv3x3(act(GroupNorm32(cat(x1, x2)) [* (1 + gamma) + beta])) [+ conv1x1_skip(cat(raw1, raw2))] + bias [+ rowvec]
         [+ residual] in ONE launch after the GroupNorm statistics (pyunet.py:262-300; taming model.py:117-137): the normalised
         operand is produced inside the conv kernel, gn_apply and its 8 B / element round trip do not exist.
@@ -424,7 +436,12 @@ class Builder:
         if rowvec is not None:
             kw.update(rowvec=rowvec["ptr"], rows_per_vec=rowvec["rows_per_vec"], ldv=rowvec["ld"], rowvec_step=rowvec.get("step"))
         self.prog.gemm(M, co, 9 * cp, None, wop, ldb=ldb, conv=geom, bias=bias_ptr, out_f32=res.ptr, ldo=co, K2=k2, tile=tile, gn=gn,
-                       gn_part=self._parts_for(res, M, co, rowvec=rowvec, residual=residual), **kw)
+                       gn_part=self._parts_for(res, M, co, rowvec=rowvec, residual=residual) if splitk <= 1 else None, **kw)
+        if splitk > 1:        # partial sums per slice -> workspace; the library launches splitk_reduce (bias, vectors, residual) behind the kernel
+            from . import tune
+            st = self.prog.ops[-1][1]
+            st.splitk, st.sk_mode = splitk, 0
+            st.ws = tune.workspace_for(st, self.device, self.prog.ws_tag + (":s1" if self.prog._sid else ""))
         self.pool.release(part)
         return res
 

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
 
     const int tiles_n = d.N / BN;
     const int nb = (d.M / BM) * tiles_n;
-    const int bid = xcd_item(nb);                     // gridDim.z == 1: XCD-contiguous tile ranges (neighbouring tiles share halo rows)
+    // (k-slice, tile) work items, XCD-contiguous like igemm_kernel's: neighbouring tiles share halo rows, a k-slice's weights sit in ONE L2
+    const int kz = xcd_item(nb) / nb;
+    const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int W = d.Ws, H = d.Hs, HW = H * W;
@@ -194,8 +196,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     // LDS byte offset of this thread's 16-byte piece in round 0 (piece q of slot s sits at q ^ (((s >> 2) & 1) << 1): conflict-free
     // ds_read_b128 fragments from ANY starting slot, which the tap shifts need); round r adds r * 128 slots = r * 8192 bytes
     const unsigned wslot = (unsigned)(((t >> 2) << 6) + (((t & 3) ^ ((((t >> 2) >> 2) & 1) << 1)) << 4));
-    const int nc = C >> 5;                            // conv chunks (Cin == C: both multiples of 32)
-    const int nraw = HASRAW ? d.K2 >> 5 : 0;
+    // split-K (gridDim.z slices, r04: the 16 x 16 planes, whose 48 tiles would leave the chip idle): slice kz takes an equal share of
+    // the conv chunks AND of the raw chunks -- every slice has the same structure and at least one conv chunk (splitk <= C / 32);
+    // partial sums go to the workspace through tile_epilogue, frido_gemm launches splitk_reduce behind this kernel
+    const int nsl = (int)gridDim.z;
+    const int nc_all = C >> 5, nraw_all = HASRAW ? d.K2 >> 5 : 0;       // (Cin == C: both multiples of 32)
+    const int cb = nc_all * kz / nsl, nc = nc_all * (kz + 1) / nsl;     // conv chunks [cb, nc)
+    const int rb = nraw_all * kz / nsl, re = nraw_all * (kz + 1) / nsl; // raw chunks [rb, re)
+    const int nraw = re - rb;
 
     auto load_unit = [&](int c, int p, CgUnit& u) {   // chunk c of the (virtually concatenated) GroupNorm input at pixel p
         const int ch = c * 32 + cu;
@@ -245,8 +253,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     const float* __restrict__ rx1 = d.raw_x1;
     const float* __restrict__ rx2 = d.raw_x2;
     const int RC1 = d.raw_C1, RC2 = d.raw_C2;
-    auto raw_load = [&](int s, CgUnit (&u)[RU]) {
-        const int ch = s * 32 + cu;
+    auto raw_load = [&](int s, CgUnit (&u)[RU]) {      // s: index within this slice's raw chunks
+        const int ch = (rb + s) * 32 + cu;
 #pragma unroll
         for (int q = 0; q < RU; ++q) {
             const int64_t p = (int64_t)m0 + q * 128 + (t >> 2);
@@ -362,11 +370,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     };
 
     // ---- prologue: weights of step 0 in flight, chunk 0 staged without overlap ----
-    issue_w(0, 0);
+    issue_w((int64_t)cb * 32, cb & 1);
     {
         CgUnit pu[NR];                 // every round's loads in flight before the first conversion (the accumulators are not live yet)
-        static_for<0, NR>([&](auto rc) { stage_load(rc, 0, pu[decltype(rc)::value]); });
-        static_for<0, NR>([&](auto rc) { stage_write(rc, std::integral_constant<int, 0>{}, 0, pu[decltype(rc)::value]); });
+        static_for<0, NR>([&](auto rc) { stage_load(rc, cb, pu[decltype(rc)::value]); });
+        static_for<0, NR>([&](auto rc) { stage_write(rc, std::integral_constant<int, 0>{}, cb, pu[decltype(rc)::value]); });
     }
 
     in_loop = true;
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             // (a) weights of the next step
             if constexpr (T < 8) issue_w((int64_t)(T + 1) * C + c * 32, (c + T + 1) & 1);
             else if constexpr (MODE == 0) issue_w((int64_t)(c + 1) * 32, (c + 1) & 1);                 // tap 0 of chunk c + 1: stage (9 (c + 1)) & 1
-            else if constexpr (MODE == 2) issue_w((int64_t)9 * C, (c + 1) & 1);                         // raw tile 0
+            else if constexpr (MODE == 2) issue_w((int64_t)9 * C + rb * 32, (c + 1) & 1);               // this slice's first raw tile
             using Y3 = std::integral_constant<int, 3>;       // (dependency only: the unit's loads completed at this step's top wait)
             if constexpr (MODE == 0) {
                 constexpr int EC = (T % 2 == 0 && T >= 2 && T / 2 - 1 < NR) ? T / 2 - 1 : -1;          // round the early waves convert
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             }
         });
     };
-    for (int c = 0; c + 1 < nc; ++c) chunk(std::integral_constant<int, 0>{}, c);
+    for (int c = cb; c + 1 < nc; ++c) chunk(std::integral_constant<int, 0>{}, c);
     if (HASRAW && nraw > 0) {
         chunk(std::integral_constant<int, 2>{}, nc - 1);
         // raw tile s: weights in stage (9 nc + s) & 1 = (nc + s) & 1, tile in patch buffer (nc + s) & 1
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (s + 1 < nraw) {
-                issue_w((int64_t)9 * C + (s + 1) * 32, (nc + s + 1) & 1);
+                issue_w((int64_t)9 * C + (rb + s + 1) * 32, (nc + s + 1) & 1);
                 raw_write(std::integral_constant<int, 3>{}, (nc + s + 1) & 1, ru);      // tile s + 1 -> the buffer step s - 1 read
                 if (s + 2 < nraw) raw_load(s + 2, ru);
             }
@@ -457,12 +465,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         chunk(std::integral_constant<int, 1>{}, nc - 1);
     }
     wait_vmcnt<0>();
-    tile_epilogue<BM, BN, 2, WM, false>(d, acc, smem, m0, n0, wave, lane, 0, 0, 0);
+    tile_epilogue<BM, BN, 2, WM, false>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
 }
 
 // eligibility of the fused GroupNorm + conv kernel (tile ids 20 = BM 256, 21 = BM 128)
 bool convgn_ok(const FridoGemm& d, int bm) {
-    if (!d.conv || d.nsplit != 2 || d.batch != 1 || d.splitk > 1 || !d.gn_x1 || !d.gn_partials || !d.gn_weight || !d.gn_bias) return false;
+    if (!d.conv || d.nsplit != 2 || d.batch != 1 || !d.gn_x1 || !d.gn_partials || !d.gn_weight || !d.gn_bias) return false;
+    if (d.splitk > 1 && (!d.ws || d.sk_mode != 0 || d.gn_part || d.splitk > ((d.gn_C1 + d.gn_C2) >> 5))) return false;
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.padx != 1 || d.up_shift || d.dn_shift || d.up2_phase) return false;
     if (d.Ho != d.Hs || d.Wo != d.Ws || d.Hl != d.Hs || d.Wl != d.Ws) return false;
     const int W = d.Ws, HW = d.Hs * d.Ws, C = d.gn_C1 + d.gn_C2;
@@ -483,13 +492,13 @@ bool convgn_ok(const FridoGemm& d, int bm) {
 
 template <int BM>
 int launch_convgn_bm(const FridoGemm& d, hipStream_t s) {
-    const int tiles = (d.M / BM) * (d.N / 192);
+    const int tiles = (d.M / BM) * (d.N / 192), sk = d.splitk > 1 ? d.splitk : 1;
     constexpr int smem = CGeo<BM>::SMEM;
     const bool sp = d.gn_gamma != nullptr, raw = d.K2 > 0;
-    if (sp && raw) hipLaunchKernelGGL((conv3x3_gn_kernel<BM, true, true>), dim3(tiles), dim3(512), smem, s, d);
-    else if (sp) hipLaunchKernelGGL((conv3x3_gn_kernel<BM, true, false>), dim3(tiles), dim3(512), smem, s, d);
-    else if (raw) hipLaunchKernelGGL((conv3x3_gn_kernel<BM, false, true>), dim3(tiles), dim3(512), smem, s, d);
-    else hipLaunchKernelGGL((conv3x3_gn_kernel<BM, false, false>), dim3(tiles), dim3(512), smem, s, d);
+    if (sp && raw) hipLaunchKernelGGL((conv3x3_gn_kernel<BM, true, true>), dim3(tiles, 1, sk), dim3(512), smem, s, d);
+    else if (sp) hipLaunchKernelGGL((conv3x3_gn_kernel<BM, true, false>), dim3(tiles, 1, sk), dim3(512), smem, s, d);
+    else if (raw) hipLaunchKernelGGL((conv3x3_gn_kernel<BM, false, true>), dim3(tiles, 1, sk), dim3(512), smem, s, d);
+    else hipLaunchKernelGGL((conv3x3_gn_kernel<BM, false, false>), dim3(tiles, 1, sk), dim3(512), smem, s, d);
     return frido_check_launch("conv3x3_gn");
 }
 

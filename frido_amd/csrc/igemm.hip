@@ -1384,8 +1384,14 @@ int launch_patch(const FridoGemm& d, int nw, hipStream_t s) {
 template <int NS, bool CONV>
 int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
     if constexpr (NS == 2 && CONV) {
-        if (tile == 20) return frido_launch_convgn(d, 256, s);
-        if (tile == 21) return frido_launch_convgn(d, 128, s);
+        if (tile == 20 || tile == 21) {
+            const int rc = frido_launch_convgn(d, tile == 20 ? 256 : 128, s);
+            if (rc == FRIDO_OK && d.splitk > 1) {        // the slices' partial sums: added up (fixed order) with the epilogue applied
+                launch_splitk_reduce(d, s);
+                return frido_check_launch("conv3x3_gn split-K reduction");
+            }
+            return rc;
+        }
     }
     if (d.gn_x1) {
         frido_set_error("igemm: a descriptor with a fused GroupNorm input (gn_x1) runs on tile 20 or 21 only");

@@ -24,6 +24,13 @@ X3_SPADE_BF16 = os.environ.get("FRIDO_X3_SPADE_BF16", "0") != "0"       # hoiste
 X3_CROSSKV_HI = os.environ.get("FRIDO_X3_CROSSKV_HI", "0") != "0"       # cached cross-attention K / V^T: residual (lo) planes zeroed
 
 
+class _Shape:
+    """Stand-in for an activation that does not exist yet (only its channel count matters to Builder.gn_conv_tile)."""
+
+    def __init__(self, C):
+        self.C, self.bf16 = C, False
+
+
 class UNetStagePlan:
     def __init__(self, b: Builder, cfg, *, B, H, W, nctx, stage, x_state, temb_rows, per_sample_t, step_ptr=None,
                  xrep=1):
@@ -217,21 +224,20 @@ class UNetStagePlan:
         n1, g1, be1 = self._norm_params(pre + ".in_layers.0")
         n2, g2, be2 = self._norm_params(pre + ".out_layers.0")
         bf16_maps = any(getattr(m, "bf16", False) for m in (g1, g2) if m is not None)
-        t1 = 0 if bf16_maps else b.gn_conv_tile(x1, x2, self.Bx, h, w, blk.cout)
+        t1, sk1 = (0, 1) if bf16_maps else b.gn_conv_tile(x1, x2, self.Bx, h, w, blk.cout)
         if t1 and has_skip:
             Craw = x1.C + (x2.C if x2 is not None else 0)
             if Craw % 64:
                 t1 = 0
-        if t1:
-            hmid = b.gn_conv(t1, x1, x2, self.Bx, h, w, n1, 1e-5, pre + ".in_layers.2", gamma=g1, beta=be1, rowvec=rv)
-            t2 = b.gn_conv_tile(hmid, None, self.Bx, h, w, blk.cout, raw=(x1, x2) if has_skip else None)
-            assert t2, "the second conv of a ResBlock sits on the same plane as the first"
+        t2, sk2 = b.gn_conv_tile(_Shape(blk.cout), None, self.Bx, h, w, blk.cout, raw=(x1, x2) if has_skip else None) if t1 else (0, 1)
+        if t1 and t2:
+            hmid = b.gn_conv(t1, x1, x2, self.Bx, h, w, n1, 1e-5, pre + ".in_layers.2", gamma=g1, beta=be1, rowvec=rv, splitk=sk1)
             if has_skip:
                 out = b.gn_conv(t2, hmid, None, self.Bx, h, w, n2, 1e-5, pre + ".out_layers.3", gamma=g2, beta=be2,
-                                skip=(x1, x2, pre + ".skip_connection"))
+                                skip=(x1, x2, pre + ".skip_connection"), splitk=sk2)
             else:
                 assert x2 is None
-                out = b.gn_conv(t2, hmid, None, self.Bx, h, w, n2, 1e-5, pre + ".out_layers.3", gamma=g2, beta=be2, residual=x1)
+                out = b.gn_conv(t2, hmid, None, self.Bx, h, w, n2, 1e-5, pre + ".out_layers.3", gamma=g2, beta=be2, residual=x1, splitk=sk2)
             hmid.free()
             return out
         a1, raw = self._norm(x1, x2, HW, pre + ".in_layers.0", 1e-5, ACT_SILU, want_raw=has_skip)

@@ -873,6 +873,11 @@ GN_CONV_CASES = [
     (16, 21, 64, 64, 192, 2, False, True, False, False),        # 16-wide plane, 128-row tiles
     (64, 20, 32, 0, 192, 1, False, False, False, False),        # a single chunk: no staging overlap at all
     (32, 21, 64, 0, 192, 1, False, True, False, False),         # two chunks + one raw chunk
+    # split-K over the chunk sequence (r04: the 16 x 16 planes): conv AND raw chunks dealt evenly to the slices, splitk_reduce behind
+    (16, 20, 192, 192, 192, 2, True, True, False, False, 3),    # 12 conv chunks + 4 raw chunks over 3 slices (one image per tile)
+    (16, 20, 576, 0, 576, 2, False, False, True, True, 5),      # 18 chunks over 5 slices (3 / 4 each), residual + producer partial sums
+    (32, 21, 96, 32, 192, 1, False, True, False, False, 4),     # 4 chunks over 4 slices: one conv chunk and one raw chunk each
+    (64, 20, 64, 0, 192, 1, True, False, False, False, 2),
 ]
 
 
@@ -882,7 +887,8 @@ def test_gn_conv_fused(case):
     input as an appended K range, + bias / timestep vector / residual in the epilogue), against F.group_norm -> F.silu -> F.conv2d in
     fp32 -- and against the two-kernel path (gn_apply + ring conv) it replaces, whose operand bits it reproduces."""
     from frido_amd.builder import ACT_SILU
-    W, tile, C1, C2, Cout, B, spade, skip, resid, from_parts = case
+    W, tile, C1, C2, Cout, B, spade, skip, resid, from_parts = case[:10]
+    splitk = case[10] if len(case) > 10 else 1
     H, C = W, C1 + C2
     HW, M = H * W, B * H * W
     Cr = 128 if skip else 0
@@ -937,9 +943,9 @@ def test_gn_conv_fused(case):
     step = torch.tensor([1], dtype=torch.int32, device="cuda")
     rv = dict(ptr=tv.data_ptr(), ld=Cout, rows_per_vec=1 << 30, step=step.data_ptr())
     out = b.gn_conv(tile, f1, f2, B, H, W, "n", 1e-5, "c", gamma=g, beta=be, act=ACT_SILU, rowvec=rv, residual=r,
-                    skip=(fr, None, "s") if skip else None)
+                    skip=(fr, None, "s") if skip else None, splitk=splitk)
     st = b.prog.ops[-1][1]
-    assert st.tile == tile and st.gn_x1 and not st.A
+    assert st.tile == tile and st.gn_x1 and not st.A and st.splitk == (splitk if splitk > 1 else 0)
     # the path it replaces, in the same program: gn_apply -> operand -> ring conv (+ skip as A2)
     a_ref, raw_ref = b.groupnorm(f1, f2, B, HW, "n", 1e-5, gamma=g, beta=be, act=ACT_SILU, want_raw=False)
     if skip:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round GPU run: full GPU test suite, then the bench lines of record.  The pinned tile cache (profiles/tune_cache.json) is
 # rewritten by the first bench invocation (--retune) and read-only afterwards.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
@@ -17,7 +17,7 @@ python tools/bench_config3.py > $OUT/${TAG}_config3_line_bf16x3.json 2>/dev/null
 python tools/bench_config5.py > $OUT/${TAG}_config5_line_bf16x3.json 2>/dev/null
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r03_*line*.json")):
+for f in sorted(glob.glob("gpurun_out/r04_*line*.json")):
     try:
         d = json.loads([l for l in open(f) if l.startswith("{")][-1])
     except Exception as e:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fused GroupNorm + 3x3 conv (csrc/convgn.inc) against the pair it replaces (gn_apply + tuned ring conv), one shape at a time,
-per-op HIP events (median of 20):   python tools/gnconv_bench.py B H W C1 C2 Cout spade(0/1) skipC [tile]"""
+per-op HIP events (median of 20):   python tools/gnconv_bench.py B H W C1 C2 Cout spade(0/1) skipC [tile] [splitk]"""
 import ctypes as C
 import os
 import sys
@@ -69,14 +69,15 @@ def main():
     for tile in ([int(sys.argv[9])] if len(sys.argv) > 9 else [20, 21]):
         prog_b = b.new_prog()
         try:
-            b.gn_conv(tile, f1, f2, B, H, W, "n", 1e-5, "c", gamma=g, beta=be, act=ACT_SILU, skip=(fr, None, "s") if Cr else None)
+            b.gn_conv(tile, f1, f2, B, H, W, "n", 1e-5, "c", gamma=g, beta=be, act=ACT_SILU, skip=(fr, None, "s") if Cr else None,
+                      splitk=int(sys.argv[10]) if len(sys.argv) > 10 else 1)
             ms = timed(prog_b, sp)
         except _lib.FridoHipError as e:
             print(f"   fused tile {tile}: n/a ({str(e)[-60:]})")
             continue
         tot = sum(ms)
         for (kind, st), t in zip(prog_b.ops, ms):
-            print(f"   fused t{tile}   {names[kind]:10s} {t * 1e3:8.1f} us")
+            print(f"   fused t{tile}   {names[kind]:10s} {t * 1e3:8.1f} us" + (f" (incl. splitk_reduce, {st.splitk} slices)" if names[kind] == "GEMM" and st.splitk > 1 else ""))
         print(f"   fused t{tile}   total      {tot * 1e3:8.1f} us   {flops / tot / 1e9:7.1f} TF/s (conv alone {flops / ms[-1] / 1e9:7.1f})")
 
 
