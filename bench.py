@@ -58,6 +58,7 @@ def gemm_roofline(eng, stream_ptr, precision):
     t_gemm = flops = n_gemm = 0
     conv_t = conv_f = 0.0
     alg_bytes = 0.0
+    per_kernel = {"conv3x3_gn_kernel": [0.0, 0.0, 0], "igemm_kernel": [0.0, 0.0, 0]}      # [ms, flops, launches]
     for (kind, st), t in zip(prog.ops, ms):
         if kind == k_gemm:
             f = 2.0 * st.M * st.N * (st.K + st.K2) * st.batch
@@ -72,6 +73,10 @@ def gemm_roofline(eng, stream_ptr, precision):
             if st.conv:
                 conv_t += t
                 conv_f += f
+            pk = per_kernel["conv3x3_gn_kernel" if st.gn_x1 else "igemm_kernel"]
+            pk[0] += t
+            pk[1] += f
+            pk[2] += 1
     total = sum(ms)
     passes = 3 if precision == "bf16x3" else 1          # MFMA passes per algorithmic product (hi*hi + hi*lo + lo*hi)
     algorithmic = flops / (t_gemm * 1e-3) / 1e12        # ALGORITHMIC 2MNK of the family / its summed launch time
@@ -122,6 +127,12 @@ def gemm_roofline(eng, stream_ptr, precision):
                 launches=n_gemm, avg_launch_us=round(1e3 * t_gemm / n_gemm, 2),
                 alg_gflop_per_launch=round(flops / n_gemm / 1e9, 3),
                 conv_tflops=round(conv_f / (conv_t * 1e-3) / 1e12, 2) if conv_t else None,
+                # the two kernels of the family separately.  conv3x3_gn_kernel (r04) does the GroupNorm-apply + SiLU + hi / lo split of its
+                # input INSIDE the launch (work that gn_apply_kernel did outside the family before): its time is not comparable 1:1 with a
+                # plain conv's, the pair it replaces (gn_apply + ring conv) is profiles/r04_gnconv_bench_v3.txt
+                per_kernel={k: dict(launches=v[2], avg_launch_us=round(1e3 * v[0] / v[2], 2), algorithmic_tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 2),
+                                    frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4), share_of_forward=round(v[0] / total, 4))
+                            for k, v in per_kernel.items() if v[2]},
                 gemm_share_of_forward=round(t_gemm / total, 4), forward_ms=round(total, 3))
 
 

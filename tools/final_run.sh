@@ -1,18 +1,19 @@
 #!/bin/bash
-# End-of-round GPU run: full GPU test suite, then the bench lines of record.  The pinned tile cache (profiles/tune_cache.json) is
-# rewritten by the first bench invocation (--retune) and read-only afterwards.
+# End-of-round GPU run.  FIRST the bench lines that (re)write the pinned tile cache for this library (profiles/tune_cache.json, keyed by
+# the library's content hash: B = 16 headline + B = 32 = config 4's per-GPU shard), THEN the full GPU suite, which reads that cache
+# (tests/conftest.py): the parity tests run on the tiles the benchmark runs on.  Then the other workloads' lines and smoke().
 TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
+rm -f profiles/tune_cache.json $OUT/e2e_error.json
+python bench.py --retune --steps 3 --warmup 1 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.err      # two-plane headline + bf16 extra + CPU baseline
+python bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline --no-bf16-extra --retune > $OUT/${TAG}_bench_line_batch32.json 2>/dev/null   # config 4's per-GPU shard (the cache gains its signatures)
+cp profiles/tune_cache.json $OUT/tune_cache.json
 (time python -m pytest tests -m gpu -q -s --durations=10 > $OUT/final_gpu_tests.log 2>&1); tail -4 $OUT/final_gpu_tests.log
 cp $OUT/e2e_error.json $OUT/${TAG}_e2e_error.json 2>/dev/null
-rm -f profiles/tune_cache.json
-python bench.py --retune --steps 3 --warmup 1 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.err      # bf16x3 headline + bf16 extra + CPU baseline
-cp profiles/tune_cache.json $OUT/tune_cache.json
 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-bf16-extra > $OUT/${TAG}_bench_line_repeat.json 2>/dev/null     # second process: pinned tiles, no tuning
-python bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline --no-bf16-extra --retune > $OUT/${TAG}_bench_line_batch32.json 2>/dev/null   # config 4's per-GPU shard (own tiles; the cache gains its signatures)
-cp profiles/tune_cache.json $OUT/tune_cache.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-extra > $OUT/${TAG}_bench_line_torchrun_n1.json 2>/dev/null   # the RCCL path (uint8 all-gather) at N = 1
 python tools/bench_config3.py > $OUT/${TAG}_config3_line_bf16x3.json 2>/dev/null
 python tools/bench_config5.py > $OUT/${TAG}_config5_line_bf16x3.json 2>/dev/null
 python - <<'PY'
