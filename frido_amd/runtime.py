@@ -122,7 +122,7 @@ class SamplerEngine:
         return self._stream
 
     def _sampler_op(self, s, *, noise_ptr, noise_C, seed, sample0, write_x=1, x_out=None, eps_out=None, hist=(),
-                    row_offset=0, hist_mode=0):
+                    row_offset=0, hist_mode=0, no_cfg=False):
         plan = self.stages[s]
         start = sum(self.embed[:s])
         nch = self.embed[s]
@@ -135,7 +135,7 @@ class SamplerEngine:
                   cfg_dev=self.cfg_dev.data_ptr())
         if hist_mode:
             kw.update(hist_ring=self.hist.data_ptr(), hist_stride=self.hist_stride, hist_mode=hist_mode)
-        if self.xrep == 2:
+        if self.xrep == 2 and not no_cfg:
             kw["eps_uncond"] = plan.eps.data_ptr() + 4 * BHW * nch
         if noise_ptr:
             kw.update(noise=noise_ptr, noise_stride=BHW * noise_C, noise_C=noise_C, noise_c0=start)
@@ -160,13 +160,25 @@ class SamplerEngine:
     # ---- main entry --------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, cond, uncond=None, *, x_T=None, noise="philox", seed=0, sample0=0, log_every_t=100, callback=None,
-            img_callback=None):
+            img_callback=None, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None, model=None):
         """Runs all stages.  noise: "philox" (device counter RNG), "torch" (draw from torch's global CPU generator in
         exactly the reference's order -- the stream of a reference run on CPU with the same torch.manual_seed), or a
         callable shape -> tensor replaying a recorded tape.  A supplied x_T is, like in the reference (ddim.py:150-152,
         plms.py:150-152), taken as the FINISHED stage-0 result: stage 0 and its pooling hand-off are skipped (with one
-        stage x_T comes back unchanged).  Returns (samples NCHW, intermediates dict)."""
+        stage x_T comes back unchanged).
+        noise_dropout (ddim.py:260-262; plms.py get_x_prev_and_pred_x0): F.dropout of the update's noise -- its keep mask comes from
+        torch's generator right after the randn, so it exists in the host-noise modes only ("torch" / a tape).
+        score_corrector (ddim.py:228-230): an arbitrary Python hook between the denoiser and the update -- the DDIM stage then runs
+        step by step on the stream (forward program, hook on torch tensors, update kernel) instead of replaying a captured graph.
+        Returns (samples NCHW, intermediates dict)."""
         B, C, H, W = self.B, self.C, self.H, self.W
+        self._opts = dict(noise_dropout=float(noise_dropout), score_corrector=score_corrector, corrector_kwargs=dict(corrector_kwargs or {}),
+                          model=model, cond=cond, uncond=uncond)
+        if noise_dropout > 0. and noise == "philox":
+            raise NotImplementedError("noise_dropout draws its keep mask from torch's generator: use noise='torch' (or a recorded tape)")
+        if score_corrector is not None and self.kind != "ddim":
+            raise NotImplementedError("score_corrector is wired into the DDIM sampler only (plms.py:236-238 applies it inside every "
+                                      "model evaluation of the multi-step scheme, which the captured PLMS graphs do not expose)")
         stream = self._stream_ptr()
         stream.wait_stream(torch.cuda.current_stream(self.dev))
         sp = stream.cuda_stream
@@ -251,6 +263,15 @@ class SamplerEngine:
         from .engine import Prog
         plan = self.stages[s]
         n = self.n_steps
+        opts = getattr(self, "_opts", {})
+        p_drop = opts.get("noise_dropout", 0.0)
+        if draw is not None and p_drop > 0.:
+            base = draw
+            # dropout(sigma * noise * temperature) = sigma * temperature * dropout(noise): applied to the host tape, mask drawn right
+            # after the step's randn like the reference does
+            draw = lambda shape: torch.nn.functional.dropout(base(shape), p=p_drop)
+        if opts.get("score_corrector") is not None:
+            return self._ddim_stage_with_corrector(s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs, opts)
         if draw is not None:
             noise_ptr, noise_C = self._upload_noise(s, [draw((self.B, Cs, self.H, self.W)) for _ in range(n)])
             key = ("ddim_tape", s)
@@ -277,6 +298,40 @@ class SamplerEngine:
             launch = (lambda: g.launch(sp)) if self.use_graph else (lambda: g.run(sp))
         for i in range(n):
             launch()
+            self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
+
+    def _ddim_stage_with_corrector(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs, opts):
+        """ddim.py:188-273 with `score_corrector.modify_score(model, e_t, x, t, c, **kwargs)` (:228-230) between the (CFG-mixed)
+        eps and the update: eager, one step at a time -- forward program, hook on torch tensors (NCHW, frozen channels
+        zero-padded like the reference's e_t), update kernel."""
+        from .engine import Prog
+        plan = self.stages[s]
+        n, B, H, W = self.n_steps, self.B, self.H, self.W
+        start, nch = sum(self.embed[:s]), self.embed[s]
+        if draw is not None:
+            noise_ptr, noise_C = self._upload_noise(s, [draw((B, Cs, H, W)) for _ in range(n)])
+        else:
+            noise_ptr, noise_C = None, 0
+            self.rng.copy_(torch.tensor([seed, sample0], dtype=torch.int64))
+        upd = Prog(self.dev, self.b.nsplit)
+        upd.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=noise_ptr, noise_C=noise_C, seed=0, sample0=0, no_cfg=True))
+        upd.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
+        corr, kw, model, cond = opts["score_corrector"], opts["corrector_kwargs"], opts["model"], opts["cond"]
+        t_steps = self.t_loop.astype(np.int64)
+        for i in range(n):
+            plan.step.run(sp)
+            e = plan.eps.view(self.xrep, B, H, W, nch).permute(0, 1, 4, 2, 3)        # [cond | uncond] x (B, nch, H, W)
+            e_t = e[0]
+            if self.xrep == 2:
+                e_t = e[1] + self.cfg_scale * (e_t - e[1])                             # ddim.py:226
+            e_t = torch.cat((torch.zeros(B, start, H, W, device=self.dev), e_t), dim=1) if start else e_t.contiguous()
+            x_now = self._to_nchw(self.x, sp)[:, :Cs]
+            t = torch.full((B,), int(t_steps[i]), device=self.dev, dtype=torch.long)
+            e_new = corr.modify_score(model, e_t, x_now, t, cond, **kw).to(torch.float32).contiguous()
+            assert e_new.shape == (B, Cs, H, W), "modify_score must return a tensor of e_t's shape"
+            _run1(self.b, "FRIDO_OP_RELAYOUT", sp, src=e_new.data_ptr(), dst=plan.eps.data_ptr(), B=B, HW=H * W, Csrc=Cs, c0=start,
+                  Cuse=nch, Cdst=nch, d0=0, to_nchw=0)
+            upd.run(sp)
             self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
 
     def _plms_stage(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs):
@@ -318,9 +373,11 @@ class SamplerEngine:
         for i in range(n):
             # eta == 0: the reference still draws (and discards) noise for every update; keep a replayed stream in step
             if draw is not None:
-                draw((self.B, Cs, self.H, self.W))
-                if i == 0:
-                    draw((self.B, Cs, self.H, self.W))
+                p_drop = getattr(self, "_opts", {}).get("noise_dropout", 0.0)
+                for _ in range(2 if i == 0 else 1):
+                    nz = draw((self.B, Cs, self.H, self.W))
+                    if p_drop > 0.:
+                        torch.nn.functional.dropout(nz, p=p_drop)      # (plms.py get_x_prev_and_pred_x0: the mask draw consumes generator state)
             go(g_first if i == 0 else g_body)
             self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
 

@@ -67,9 +67,14 @@ class _SamplerBase:
                score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1., unconditional_conditioning=None, noise="torch", seed=0, sample0=0,
                replica=0, **kwargs):
-        if mask is not None or x0 is not None or score_corrector is not None or quantize_x0 or noise_dropout > 0.:
-            raise NotImplementedError("mask / x0 / score_corrector / quantize_x0 / noise_dropout are not on the HIP path "
-                                      "(no shipped Frido sampling script uses them; quantize_x0 exit()s in the reference)")
+        if mask is not None or x0 is not None:
+            # ddim.py:158-161 / plms.py blend `q_sample(x0, ts) * mask + (1 - mask) * img`, but img carries only the channels of the
+            # stages reached so far: with num_stage > 1 -- every Frido model -- the reference itself raises a RuntimeError (size
+            # mismatch) in stage 0 (full-channel x0) or in stage 1 (stage-0-channel x0); verified against the reference on CPU
+            raise NotImplementedError("mask / x0 (inpainting): the reference's blend fails for multi-stage models (shape mismatch between "
+                                      "x0 and the per-stage latent, ddim.py:158-161); not provided on the HIP path")
+        if quantize_x0:
+            raise NotImplementedError("quantize_x0: the reference calls exit() on this option (ddim.py:251-253)")
         if conditioning is None or isinstance(conditioning, dict):
             raise NotImplementedError("cross-attention conditioning tensor required")
         if conditioning.shape[0] != batch_size:
@@ -90,7 +95,8 @@ class _SamplerBase:
             print(f"Data shape for {self.KIND.upper()} sampling is {(batch_size, *shape)}, eta {eta}")
         self.num_stage = num_stage
         return eng.run(conditioning, unconditional_conditioning, x_T=x_T, noise=noise, seed=seed, sample0=sample0,
-                       log_every_t=log_every_t, callback=callback, img_callback=img_callback)
+                       log_every_t=log_every_t, callback=callback, img_callback=img_callback, noise_dropout=noise_dropout,
+                       score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, model=self.model)
 
 
 class DDIMSampler(_SamplerBase):

@@ -61,15 +61,19 @@ def _model_eps(apply_model, x, t, c, s, start, scale, uc):
     return e_t
 
 
-def _x_prev(x, e_t, a_t, a_prev, sigma_t, sqrt1m, start, noise, temperature=1.0):
-    """ddim.py:237-268: all coefficients are fp32 (B,1,1,1) tensors built with torch.full."""
+def _x_prev(x, e_t, a_t, a_prev, sigma_t, sqrt1m, start, noise, temperature=1.0, noise_dropout=0.0):
+    """ddim.py:237-268: all coefficients are fp32 (B,1,1,1) tensors built with torch.full; noise_dropout: ddim.py:260-262
+    (F.dropout of the scaled noise: draws its keep mask from torch's global generator right after the randn)."""
     b = x.shape[0]
     full = lambda v: torch.full((b, 1, 1, 1), float(v))
     a_t, a_prev, sigma_t, sqrt1m = full(a_t), full(a_prev), full(sigma_t), full(sqrt1m)
     pred_x0 = (x - sqrt1m * e_t) / a_t.sqrt()
     pred_x0[:, :start] = x[:, :start]
     dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
-    x_prev = a_prev.sqrt() * pred_x0 + dir_xt + sigma_t * noise * temperature
+    nz = sigma_t * noise * temperature
+    if noise_dropout > 0.:
+        nz = F.dropout(nz, p=noise_dropout)
+    x_prev = a_prev.sqrt() * pred_x0 + dir_xt + nz
     x_prev[:, :start] = pred_x0[:, :start]
     return x_prev, pred_x0
 
@@ -88,9 +92,10 @@ def _handoff(img, s, num_stage, embed):
 
 @torch.no_grad()
 def ddim_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, eta=0.0, scale=1.0, uc=None,
-                noise=None, log_every_t=100, temperature=1.0, x_T=None):
+                noise=None, log_every_t=100, temperature=1.0, x_T=None, noise_dropout=0.0, score_corrector=None):
     """ddim.py:116-186.  apply_model(x, t, cond, stage) -> eps of that stage.  A supplied x_T is adopted as the finished
-    stage-0 result (ddim.py:150-152: stage 0 and its hand-off are skipped)."""
+    stage-0 result (ddim.py:150-152: stage 0 and its hand-off are skipped).  score_corrector: callable (e_t, x, t, cond) -> e_t
+    applied after the CFG mix (ddim.py:228-230: `score_corrector.modify_score(model, e_t, x, t, c, **kwargs)`)."""
     noise = noise or NoiseSource()
     ts = ddim_timesteps(S)
     sig, al, alp = ddim_params(ac32, ts, eta)
@@ -112,8 +117,10 @@ def ddim_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, eta
             index = total - i - 1
             t = torch.full((b,), int(step), dtype=torch.long)
             e_t = _model_eps(apply_model, img, t, cond, s, start, scale, uc)
+            if score_corrector is not None:
+                e_t = score_corrector(e_t, img, t, cond)
             img, pred_x0 = _x_prev(img, e_t, al[index], alp[index], sig[index], sq1m[index], start,
-                                   noise(img.shape), temperature)
+                                   noise(img.shape), temperature, noise_dropout)
             if index % log_every_t == 0 or index == total - 1:
                 inter["x_inter"].append(img)
                 inter["pred_x0"].append(pred_x0)

@@ -256,6 +256,47 @@ def gen_sampler(tag, ucfg, vcfg, bcfg, B, nctx):
 # incompressible floats): the runs draw from torch's CPU generator after torch.manual_seed(23), which the HIP samplers'
 # noise="torch" mode reproduces draw for draw; a checksum of the stream is stored so that a generator mismatch is
 # reported as such.
+class GoldenCorrector:
+    """A score corrector in the reference's protocol (ddim.py:228-230): deterministic, depends on e_t, x and t."""
+
+    def modify_score(self, model, e_t, x, t, c, gain=1.0):
+        return gain * e_t + 0.01 * torch.tanh(x) * (t.float().view(-1, 1, 1, 1) / 1000.0)
+
+
+def gen_sampler_opts():
+    """Sampler options of ddim.py the shipped scripts do not use (r04): noise_dropout (ddim.py:260-262) and score_corrector
+    (ddim.py:228-230), on the small 2-stage config.  The runs draw from torch's CPU generator after manual_seed(23): randn AND
+    dropout masks -- the HIP sampler's noise="torch" mode makes the same draws in the same order."""
+    DDIM, PLMS = H.patch_samplers()
+    model = build_frido(UNET_SMALL, VQ_SMALL, BERT_SMALL)
+    B, nctx = 2, 5
+    tokens = torch.from_numpy(np.random.default_rng(5).integers(0, BERT_SMALL["vocab_size"], (B, nctx)))
+    with torch.no_grad():
+        c = model.get_learned_conditioning(tokens)
+        uc = torch.zeros_like(c)
+    out = {"c": c.numpy()}
+    for name, kw in (("dropout", dict(eta=1.0, noise_dropout=0.25)),
+                     ("corrector", dict(eta=1.0, score_corrector=GoldenCorrector(), corrector_kwargs=dict(gain=0.9))),
+                     ("corrector_cfg_dropout", dict(eta=0.5, noise_dropout=0.4, score_corrector=GoldenCorrector(), corrector_kwargs=dict(gain=1.1),
+                                                    unconditional_guidance_scale=1.5, unconditional_conditioning=uc))):
+        torch.manual_seed(23)
+        with torch.no_grad():
+            samples, inter = DDIM(model).sample(S=5, batch_size=B, shape=(6, 16, 16), conditioning=c, num_stage=2, verbose=False,
+                                                log_every_t=2, **kw)
+        out[f"{name}_samples"] = samples.numpy()
+        out[f"{name}_pred_x0_1"] = inter["pred_x0"][1].numpy()
+        out[f"{name}_nx"] = np.int64(len(inter["x_inter"]))
+    # PLMS with dropout: eta = 0, the dropout only consumes generator state (plms.py:247-303)
+    torch.manual_seed(23)
+    with torch.no_grad():
+        samples, _ = PLMS(model).sample(S=5, batch_size=B, shape=(6, 16, 16), conditioning=c, num_stage=2, verbose=False, log_every_t=2,
+                                        noise_dropout=0.3)
+        tail = torch.randn(4)             # the generator's state after the run: every draw (randn + dropout masks) was consumed
+    out["plms_dropout_samples"] = samples.numpy()
+    out["plms_dropout_rng_tail"] = tail.numpy()
+    save("sampler_opts", **out)
+
+
 def _decode_with_codes(model, samples):
     """decode_first_stage (frido.py:823-891) + the per-scale codes (the reference drops return_code for VQ first stages)."""
     z = samples.clone()
@@ -465,6 +506,7 @@ GENS = {
     "vq_small": lambda: gen_vq("vq_small", VQ_SMALL, B=2),
     "vq_full": lambda: gen_vq("vq_full", VQ_FULL, B=1, subsample=8),
     "sampler_small": lambda: gen_sampler("sampler_small", UNET_SMALL, VQ_SMALL, BERT_SMALL, B=2, nctx=5),
+    "sampler_opts": gen_sampler_opts,
     "sampler_small3": lambda: gen_sampler("sampler_small3", UNET_SMALL3, VQ_SMALL3, BERT_SMALL, B=1, nctx=7),
     "sampler_xt": gen_sampler_xt,
     "vq_full_enc": gen_vq_full_enc,

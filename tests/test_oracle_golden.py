@@ -242,3 +242,27 @@ def test_vq_full_width_encode_oracle():
     x = torch.from_numpy(np.tanh(seeded_normal("vq_full:img", (1, 3, 256, 256))))
     enc = vq_encode(sd, VQ_FULL, x)
     assert enc.shape == g["enc"].shape and float((enc - torch.from_numpy(g["enc"])).abs().max()) < 2e-5
+
+
+def _golden_corrector(gain):
+    """tests/golden/make_golden.py GoldenCorrector.modify_score in the oracle's callable form."""
+    return lambda e_t, x, t, c: gain * e_t + 0.01 * torch.tanh(x) * (t.float().view(-1, 1, 1, 1) / 1000.0)
+
+
+def test_sampler_options_oracle_bit_exact():
+    """ddim.py:228-230 (score_corrector) and :260-262 (noise_dropout) against the reference's own runs (sampler_opts fixture): the
+    oracle draws randn AND the dropout masks from torch's CPU generator in the reference's order, so the same seed gives the
+    same samples, bit for bit."""
+    g = golden("sampler_opts")
+    c = torch.from_numpy(g["c"])
+    usd = synth_sd(unet_holder(UNET_SMALL), "model.diffusion_model.")
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    am = lambda x, t, cond, s: unet_forward(usd, UNET_SMALL, x, t, cond, s)
+    runs = (("dropout", dict(eta=1.0, noise_dropout=0.25)),
+            ("corrector", dict(eta=1.0, score_corrector=_golden_corrector(0.9))),
+            ("corrector_cfg_dropout", dict(eta=0.5, noise_dropout=0.4, score_corrector=_golden_corrector(1.1), scale=1.5, uc=torch.zeros_like(c))))
+    for name, kw in runs:
+        torch.manual_seed(23)
+        out, inter = S.ddim_sample(am, ac, 5, (2, 6, 16, 16), c, [3, 3], [3, 3], 2, log_every_t=2, **kw)
+        assert torch.equal(out, torch.from_numpy(g[f"{name}_samples"])), name
+        assert torch.equal(inter["pred_x0"][1], torch.from_numpy(g[f"{name}_pred_x0_1"])) and len(inter["x_inter"]) == int(g[f"{name}_nx"])
