@@ -64,6 +64,8 @@ def gemm_roofline(eng, stream_ptr, precision):
             f = 2.0 * st.M * st.N * (st.K + st.K2) * st.batch
             esz = 2 * st.nsplit
             a_b = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin * esz if st.conv else st.M * st.K * esz * st.batch
+            if st.gn_x1:      # fused GroupNorm + conv: the f32 stream (4 B / element) [+ the two SPADE maps] [+ the raw f32 rows of the skip conv]
+                a_b = st.M * st.Cin * 4 * (3 if st.gn_gamma else 1) + st.M * st.K2 * 4
             o_b = st.M * (st.N // 2 if st.geglu else st.N) * st.batch * ((2 if st.out_bf16 else 4) * bool(st.out_f32) + esz * bool(st.out_op))
             r_b = st.M * st.N * (2 if st.res_bf16 else 4) if st.residual else 0
             alg_bytes += a_b + st.N * st.K * esz * (1 if not st.b_bs else st.batch) + o_b + r_b
