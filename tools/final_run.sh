@@ -9,6 +9,7 @@ cd $R
 rm -f profiles/tune_cache.json $OUT/e2e_error.json
 python bench.py --retune --steps 3 --warmup 1 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.err      # two-plane headline + bf16 extra + CPU baseline
 python bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline --no-bf16-extra --retune > $OUT/${TAG}_bench_line_batch32.json 2>/dev/null   # config 4's per-GPU shard (the cache gains its signatures)
+python bench.py --steps 1 --warmup 0 --batch 1 --ddim-steps 4 --no-cpu-baseline --no-bf16-extra --retune > /dev/null 2>&1   # B = 1 at full width: the shapes of the config-1 / config-2-step goldens and of the rows-vs-B=1 tests
 cp profiles/tune_cache.json $OUT/tune_cache.json
 (time python -m pytest tests -m gpu -q -s --durations=10 > $OUT/final_gpu_tests.log 2>&1); tail -4 $OUT/final_gpu_tests.log
 cp $OUT/e2e_error.json $OUT/${TAG}_e2e_error.json 2>/dev/null
