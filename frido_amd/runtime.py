@@ -176,9 +176,6 @@ class SamplerEngine:
                           model=model, cond=cond, uncond=uncond)
         if noise_dropout > 0. and noise == "philox":
             raise NotImplementedError("noise_dropout draws its keep mask from torch's generator: use noise='torch' (or a recorded tape)")
-        if score_corrector is not None and self.kind != "ddim":
-            raise NotImplementedError("score_corrector is wired into the DDIM sampler only (plms.py:236-238 applies it inside every "
-                                      "model evaluation of the multi-step scheme, which the captured PLMS graphs do not expose)")
         stream = self._stream_ptr()
         stream.wait_stream(torch.cuda.current_stream(self.dev))
         sp = stream.cuda_stream
@@ -300,14 +297,32 @@ class SamplerEngine:
             launch()
             self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
 
+    def _corrected_eps(self, s, sp, Cs, t_value, opts):
+        """`score_corrector.modify_score(model, e_t, x, t, c, **kwargs)` (ddim.py:228-230, plms.py:236-238) on the eps the forward
+        program just wrote: CFG mix (ddim.py:226), frozen channels zero-padded like the reference's e_t, hook on torch tensors
+        (NCHW), active channels written back as the (already mixed) conditional eps the update kernel reads."""
+        plan = self.stages[s]
+        B, H, W = self.B, self.H, self.W
+        start, nch = sum(self.embed[:s]), self.embed[s]
+        e = plan.eps.view(self.xrep, B, H, W, nch).permute(0, 1, 4, 2, 3)            # [cond | uncond] x (B, nch, H, W)
+        e_t = e[0]
+        if self.xrep == 2:
+            e_t = e[1] + self.cfg_scale * (e_t - e[1])
+        e_t = torch.cat((torch.zeros(B, start, H, W, device=self.dev), e_t), dim=1) if start else e_t.contiguous()
+        x_now = self._to_nchw(self.x, sp)[:, :Cs]
+        t = torch.full((B,), int(t_value), device=self.dev, dtype=torch.long)
+        e_new = opts["score_corrector"].modify_score(opts["model"], e_t, x_now, t, opts["cond"], **opts["corrector_kwargs"])
+        e_new = e_new.to(torch.float32).contiguous()
+        assert e_new.shape == (B, Cs, H, W), "modify_score must return a tensor of e_t's shape"
+        _run1(self.b, "FRIDO_OP_RELAYOUT", sp, src=e_new.data_ptr(), dst=plan.eps.data_ptr(), B=B, HW=H * W, Csrc=Cs, c0=start,
+              Cuse=nch, Cdst=nch, d0=0, to_nchw=0)
+
     def _ddim_stage_with_corrector(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs, opts):
-        """ddim.py:188-273 with `score_corrector.modify_score(model, e_t, x, t, c, **kwargs)` (:228-230) between the (CFG-mixed)
-        eps and the update: eager, one step at a time -- forward program, hook on torch tensors (NCHW, frozen channels
-        zero-padded like the reference's e_t), update kernel."""
+        """ddim.py:188-273 with the score corrector between the (CFG-mixed) eps and the update: eager, one step at a time --
+        forward program, hook, update kernel."""
         from .engine import Prog
         plan = self.stages[s]
         n, B, H, W = self.n_steps, self.B, self.H, self.W
-        start, nch = sum(self.embed[:s]), self.embed[s]
         if draw is not None:
             noise_ptr, noise_C = self._upload_noise(s, [draw((B, Cs, H, W)) for _ in range(n)])
         else:
@@ -316,22 +331,52 @@ class SamplerEngine:
         upd = Prog(self.dev, self.b.nsplit)
         upd.emit("FRIDO_OP_SAMPLER_STEP", **self._sampler_op(s, noise_ptr=noise_ptr, noise_C=noise_C, seed=0, sample0=0, no_cfg=True))
         upd.emit("FRIDO_OP_STEP_ADD", step=self.step.data_ptr(), delta=1)
-        corr, kw, model, cond = opts["score_corrector"], opts["corrector_kwargs"], opts["model"], opts["cond"]
         t_steps = self.t_loop.astype(np.int64)
         for i in range(n):
             plan.step.run(sp)
-            e = plan.eps.view(self.xrep, B, H, W, nch).permute(0, 1, 4, 2, 3)        # [cond | uncond] x (B, nch, H, W)
-            e_t = e[0]
-            if self.xrep == 2:
-                e_t = e[1] + self.cfg_scale * (e_t - e[1])                             # ddim.py:226
-            e_t = torch.cat((torch.zeros(B, start, H, W, device=self.dev), e_t), dim=1) if start else e_t.contiguous()
-            x_now = self._to_nchw(self.x, sp)[:, :Cs]
-            t = torch.full((B,), int(t_steps[i]), device=self.dev, dtype=torch.long)
-            e_new = corr.modify_score(model, e_t, x_now, t, cond, **kw).to(torch.float32).contiguous()
-            assert e_new.shape == (B, Cs, H, W), "modify_score must return a tensor of e_t's shape"
-            _run1(self.b, "FRIDO_OP_RELAYOUT", sp, src=e_new.data_ptr(), dst=plan.eps.data_ptr(), B=B, HW=H * W, Csrc=Cs, c0=start,
-                  Cuse=nch, Cdst=nch, d0=0, to_nchw=0)
+            self._corrected_eps(s, sp, Cs, t_steps[i], opts)
             upd.run(sp)
+            self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
+
+    def _plms_stage_with_corrector(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs, opts):
+        """plms.py:156-194,198-303 with the score corrector inside every model evaluation (plms.py:236-238): the op sequences of
+        the two captured PLMS programs, run eagerly with the hook after each forward.  The corrected eps is what enters the
+        Adams-Bashforth history ring (plms.py:175-177 appends get_model_output's result)."""
+        from .engine import Prog
+        plan = self.stages[s]
+        n = self.n_steps
+        self.rng.copy_(torch.tensor([seed, sample0], dtype=torch.int64))
+        nbytes = self.x.numel() * 4
+
+        def prog(*ops):
+            p = Prog(self.dev, self.b.nsplit)
+            for kind, kw in ops:
+                p.emit(kind, **kw)
+            return p
+        step_add = lambda d: ("FRIDO_OP_STEP_ADD", dict(step=self.step.data_ptr(), delta=d))
+        upd = lambda mode: ("FRIDO_OP_SAMPLER_STEP", self._sampler_op(s, noise_ptr=None, noise_C=0, seed=0, sample0=0, hist_mode=mode, no_cfg=True))
+        save = ("FRIDO_OP_COPY", dict(src=self.x.data_ptr(), dst=self.x_save.data_ptr(), n=nbytes))
+        restore = ("FRIDO_OP_COPY", dict(src=self.x_save.data_ptr(), dst=self.x.data_ptr(), n=nbytes))
+        first_a = prog(save, upd(1), *([step_add(1)] if n > 1 else []))            # ... then the forward at (x_prev, t_next)
+        first_b = prog(*([step_add(-1)] if n > 1 else []), restore, upd(3), step_add(1))
+        body = prog(upd(1), step_add(1))
+        t_steps = self.t_loop.astype(np.int64)
+        p_drop = opts.get("noise_dropout", 0.0)
+        for i in range(n):
+            if draw is not None:          # eta == 0: the reference still draws (and discards) noise for every update
+                for _ in range(2 if i == 0 else 1):
+                    nz = draw((self.B, Cs, self.H, self.W))
+                    if p_drop > 0.:
+                        torch.nn.functional.dropout(nz, p=p_drop)
+            plan.step.run(sp)
+            self._corrected_eps(s, sp, Cs, t_steps[i], opts)
+            if i == 0:
+                first_a.run(sp)
+                plan.step.run(sp)
+                self._corrected_eps(s, sp, Cs, t_steps[min(i + 1, n - 1)], opts)      # t_next (plms.py:164-166)
+                first_b.run(sp)
+            else:
+                body.run(sp)
             self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
 
     def _plms_stage(self, s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs):
@@ -341,6 +386,9 @@ class SamplerEngine:
         the ring history selected by the device step counter, step+1].  eta == 0 (plms.py:25-26), so no noise enters the
         update and the same graphs serve the philox / torch / tape modes."""
         from .engine import Prog
+        opts = getattr(self, "_opts", {})
+        if opts.get("score_corrector") is not None:
+            return self._plms_stage_with_corrector(s, sp, draw, seed, sample0, inter, log_every_t, callback, img_callback, Cs, opts)
         plan = self.stages[s]
         n = self.n_steps
         self.rng.copy_(torch.tensor([seed, sample0], dtype=torch.int64))

@@ -131,8 +131,9 @@ def ddim_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, eta
 
 @torch.no_grad()
 def plms_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, scale=1.0, uc=None, noise=None,
-                log_every_t=100, x_T=None):
-    """plms.py:116-303 (eta must be 0, plms.py:25-26; noise is still drawn every update; x_T: plms.py:150-152)."""
+                log_every_t=100, x_T=None, score_corrector=None):
+    """plms.py:116-303 (eta must be 0, plms.py:25-26; noise is still drawn every update; x_T: plms.py:150-152).
+    score_corrector: callable (e_t, x, t, cond) -> e_t applied inside EVERY model evaluation (plms.py:236-238)."""
     noise = noise or NoiseSource()
     ts = ddim_timesteps(S)
     sig, al, alp = ddim_params(ac32, ts, 0.0)
@@ -157,10 +158,14 @@ def plms_sample(apply_model, ac32, S, shape, cond, splits, embed, num_stage, sca
             t = torch.full((b,), int(step), dtype=torch.long)
             t_next = torch.full((b,), int(time_range[min(i + 1, total - 1)]), dtype=torch.long)
             upd = lambda e: _x_prev(img, e, al[index], alp[index], sig[index], sq1m[index], start, noise(img.shape))
-            e_t = _model_eps(apply_model, img, t, cond, s, start, scale, uc)
+
+            def model_out(xx, tt):
+                e = _model_eps(apply_model, xx, tt, cond, s, start, scale, uc)
+                return score_corrector(e, xx, tt, cond) if score_corrector is not None else e
+            e_t = model_out(img, t)
             if len(old) == 0:
                 x_p, _ = upd(e_t)
-                e_next = _model_eps(apply_model, x_p, t_next, cond, s, start, scale, uc)
+                e_next = model_out(x_p, t_next)
                 e_p = (e_t + e_next) / 2
             elif len(old) == 1:
                 e_p = (3 * e_t - old[-1]) / 2

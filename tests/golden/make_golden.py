@@ -294,6 +294,17 @@ def gen_sampler_opts():
         tail = torch.randn(4)             # the generator's state after the run: every draw (randn + dropout masks) was consumed
     out["plms_dropout_samples"] = samples.numpy()
     out["plms_dropout_rng_tail"] = tail.numpy()
+    # PLMS with a score corrector (applied inside every model evaluation, plms.py:236-238), with and without CFG
+    for name, kw in (("plms_corrector", dict(score_corrector=GoldenCorrector(), corrector_kwargs=dict(gain=0.9))),
+                     ("plms_corrector_cfg", dict(score_corrector=GoldenCorrector(), corrector_kwargs=dict(gain=1.1),
+                                                 unconditional_guidance_scale=1.5, unconditional_conditioning=uc))):
+        torch.manual_seed(23)
+        with torch.no_grad():
+            samples, inter = PLMS(model).sample(S=6, batch_size=B, shape=(6, 16, 16), conditioning=c, num_stage=2, verbose=False,
+                                                log_every_t=2, **kw)
+        out[f"{name}_samples"] = samples.numpy()
+        out[f"{name}_pred_x0_1"] = inter["pred_x0"][1].numpy()
+        out[f"{name}_nx"] = np.int64(len(inter["x_inter"]))
     save("sampler_opts", **out)
 
 

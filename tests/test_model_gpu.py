@@ -994,8 +994,14 @@ def test_sampler_options_noise_dropout_and_score_corrector():
     assert np.array_equal(torch.randn(4).numpy(), g["plms_dropout_rng_tail"]), "the run must consume the generator like the reference (randn + dropout masks)"
     with pytest.raises(NotImplementedError):
         DDIMSampler(model).sample(**dict(base, noise="philox"), noise_dropout=0.1)
-    with pytest.raises(NotImplementedError):
-        PLMSSampler(model).sample(**base, score_corrector=_GoldenCorrector())
+    for name, kw in (("plms_corrector", dict(score_corrector=_GoldenCorrector(), corrector_kwargs=dict(gain=0.9))),
+                     ("plms_corrector_cfg", dict(score_corrector=_GoldenCorrector(), corrector_kwargs=dict(gain=1.1),
+                                                 unconditional_guidance_scale=1.5, unconditional_conditioning=uc))):
+        torch.manual_seed(23)
+        samples, inter = PLMSSampler(model).sample(**dict(base, S=6), **kw)      # corrector inside every model evaluation (plms.py:236-238)
+        r = _rel(samples, g[f"{name}_samples"])
+        print(f"sampler option {name}: latent rel err {r:.2e}")
+        assert r < 1e-3 and len(inter["x_inter"]) == int(g[f"{name}_nx"]) and _rel(inter["pred_x0"][1], g[f"{name}_pred_x0_1"]) < 1e-3, name
     with pytest.raises(NotImplementedError):        # the reference's own blend raises for multi-stage models (ddim.py:158-161)
         DDIMSampler(model).sample(**base, mask=torch.ones(2, 1, 16, 16), x0=torch.zeros(2, 6, 16, 16))
 

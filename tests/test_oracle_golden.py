@@ -266,3 +266,9 @@ def test_sampler_options_oracle_bit_exact():
         out, inter = S.ddim_sample(am, ac, 5, (2, 6, 16, 16), c, [3, 3], [3, 3], 2, log_every_t=2, **kw)
         assert torch.equal(out, torch.from_numpy(g[f"{name}_samples"])), name
         assert torch.equal(inter["pred_x0"][1], torch.from_numpy(g[f"{name}_pred_x0_1"])) and len(inter["x_inter"]) == int(g[f"{name}_nx"])
+    for name, kw in (("plms_corrector", dict(score_corrector=_golden_corrector(0.9))),
+                     ("plms_corrector_cfg", dict(score_corrector=_golden_corrector(1.1), scale=1.5, uc=torch.zeros_like(c)))):
+        torch.manual_seed(23)
+        out, inter = S.plms_sample(am, ac, 6, (2, 6, 16, 16), c, [3, 3], [3, 3], 2, log_every_t=2, **kw)
+        assert torch.equal(out, torch.from_numpy(g[f"{name}_samples"])), name
+        assert torch.equal(inter["pred_x0"][1], torch.from_numpy(g[f"{name}_pred_x0_1"])) and len(inter["x_inter"]) == int(g[f"{name}_nx"])

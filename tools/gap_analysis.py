@@ -2,8 +2,9 @@
 """Idle-gap analysis of one captured sampling pass from a rocprofv3 kernel trace.
    rocprofv3 --kernel-trace --output-format csv -d DIR -- python bench.py --steps 1 --warmup 0
    python tools/gap_analysis.py DIR > summary.json
-Takes the kernels after the last randn_kernel (= the last sampling pass + decode), and reports wall time, the union of
-kernel intervals (busy), the idle remainder, and the per-kernel-name totals."""
+Takes the kernels after the last randn_kernel up to the first host round trip (a gap > 5 ms: bench.py's result checks and its
+per-op event timing follow the pass; inside a graph-launched pass no gap comes near that), i.e. one sampling pass, and reports
+wall time, the union of kernel intervals (busy), the idle remainder, and the per-kernel-name totals."""
 import csv
 import glob
 import json
@@ -28,6 +29,14 @@ def main():
     own = lambda n: not (n.startswith("at::native") or n.startswith("void at::native") or n.startswith("__amd_rocclr"))
     end = max(i for i, r in enumerate(rows) if own(r[2]))
     rows = rows[:end + 1]
+    cur = rows[0][1]
+    for i, (s0, e0, _) in enumerate(rows):
+        if i > 1000 and s0 - cur > 5_000_000:          # first host round trip after the pass
+            rows = rows[:i]
+            break
+        cur = max(cur, e0)
+    while not own(rows[-1][2]):                          # trailing torch kernels of the check that caused the round trip
+        rows.pop()
     wall = rows[-1][1] - rows[0][0]
     busy, cur_end, gaps = 0, rows[0][0], []
     before, after, prev = defaultdict(lambda: [0, 0]), defaultdict(lambda: [0, 0]), rows[0][2]
