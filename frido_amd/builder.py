@@ -15,6 +15,8 @@ ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample convs as four 2x2 phase convolutions
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
+# r04: a split-K GEMM whose output goes straight into a one-launch GroupNorm leaves its reduction to that launch (no splitk_reduce)
+SK_DEFER = os.environ.get("FRIDO_SK_DEFER", "1") != "0"
 GN_EPI_STATS = os.environ.get("FRIDO_GN_EPI_STATS", "1") != "0"   # GroupNorm partial sums from the producing GEMM's epilogue (bf16x3 f32 stream)
 LN_IN_ATTN = os.environ.get("FRIDO_LN_IN_ATTN", "1") != "0"       # norm2 / norm3 of a transformer block from the attention kernel's epilogue (A/B switch)
 ATTN_FLASH = os.environ.get("FRIDO_ATTN_FLASH", "1") != "0"       # flash-style kernel for long key sequences (flash.hip)
@@ -463,9 +465,31 @@ class Builder:
                        x_bf16=int(xb))
         return part, S
 
+    def _deferred_splitk(self, x1, M, x1_dead):
+        """r04: if the op emitted LAST is the split-K GEMM that writes x1, its reduction moves into the GroupNorm launch being emitted
+        (FridoGemm.sk_mode 2 + FridoGnApply.sk_*): the slices are added, the GEMM's epilogue applied and the statistics taken from
+        the same registers -- one launch (splitk_reduce) and one round trip of the tensor less.  Only the IMMEDIATE successor
+        qualifies: nothing can have read x1, or reused the workspace, in between.  Returns the sk_* fields (or {})."""
+        if not (SK_DEFER and self.nsplit == 2 and self.prog.ops and not getattr(x1, "bf16", False)):
+            return {}
+        kind, st = self.prog.ops[-1]
+        if (kind != _lib.OP_KINDS["FRIDO_OP_GEMM"] or st.splitk <= 1 or st.sk_mode != 0 or st.tile in (9, 10, 20, 21)
+                or getattr(st, "_sid", 0) != self.prog._sid):
+            return {}
+        if (st.out_f32 != x1.ptr or st.M != M or st.N != x1.C or st.ldo != st.N or st.N % 8 or st.batch != 1 or st.act or st.geglu
+                or st.row_bias or st.out_op or st.out_u8 or st.out_bf16 or st.up2_phase or (st.residual and st.res_bf16)
+                or (st.rowvec and st.rows_per_vec <= 0)):
+            return {}
+        st.sk_mode = 2
+        self.prog._packed = None
+        return dict(sk_ws=st.ws + _lib.SPLITK_HEADER_BYTES, sk_n=st.splitk, sk_alpha=st.alpha, sk_bias=st.bias, sk_rowvec=st.rowvec,
+                    sk_rowvec_step=st.rowvec_step, sk_rows_per_vec=st.rows_per_vec, sk_ldv=st.ldv, sk_residual=st.residual,
+                    sk_ldr=st.ldr, sk_out=None if x1_dead else st.out_f32)
+
     def groupnorm(self, x1, x2, B, HW, wname, eps, *, gamma=None, beta=None, act=ACT_NONE, want_raw=False,
-                  out_f32=False):
-        """GroupNorm(32) [+SPADE] [+SiLU] of the (virtually concatenated) NHWC f32 input -> operand."""
+                  out_f32=False, x1_dead=False):
+        """GroupNorm(32) [+SPADE] [+SiLU] of the (virtually concatenated) NHWC f32 input -> operand.  x1_dead: nothing after this
+        op reads x1 (lets a deferred split-K reduction skip materialising it)."""
         C = x1.C + (x2.C if x2 is not None else 0)
         a = self.op(B * HW, C)
         xb = getattr(x1, "bf16", False)
@@ -482,6 +506,7 @@ class Builder:
         # one launch (statistics + apply from registers) wherever a (sample, group-chunk) slice fits a workgroup
         _, probe = _lib.make_op("FRIDO_OP_GN_FUSED", **kw)
         if GN_FUSED and HW <= GN_FUSED_MAX_HW and _lib.lib().frido_gn_fused_chunk(C_.byref(probe), None) > 0:
+            kw.update(self._deferred_splitk(x1, B * HW, x1_dead))
             self.prog.emit("FRIDO_OP_GN_FUSED", **kw)
             part = None
         else:

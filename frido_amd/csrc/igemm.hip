@@ -1341,7 +1341,7 @@ int launch(const FridoGemm& d, hipStream_t s) {
     dd.sk_mode = 0;
     if (sk > 1) dd.gn_part = nullptr;                       // (validated: only sk_mode 1 may carry gn_part under split-K)
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NS, CONV, BK, W8>), dim3(tiles, d.batch, sk), dim3(Geo<BM, BN, NS, BK, W8>::NT), smem, s, dd);
-    if (sk > 1) {
+    if (sk > 1 && d.sk_mode != 2) {                         // (sk_mode 2: the consuming GroupNorm launch adds the slices up)
         launch_splitk_reduce(dd, s);
     }
     return frido_check_launch("igemm");
@@ -1544,7 +1544,14 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     if (d.splitk > 1) {
         FRIDO_REQUIRE(d.batch == 1 && d.ws != nullptr, "split-K needs batch == 1 and a workspace");
         FRIDO_REQUIRE(d.splitk <= ((d.K + d.K2) >> 6), "more K slices than k-tiles");
-        FRIDO_REQUIRE(d.sk_mode == 0 || d.sk_mode == 1, "sk_mode must be 0 or 1");
+        FRIDO_REQUIRE(d.sk_mode >= 0 && d.sk_mode <= 2, "sk_mode must be 0, 1 or 2");
+        if (d.sk_mode == 2) {
+            const int tl = d.tile ? d.tile : pick_tile(d);
+            FRIDO_REQUIRE(tl != 9 && tl != 10 && tl != 20 && tl != 21, "sk_mode 2 (reduction left to the consumer): ring kernels only");
+            FRIDO_REQUIRE(d.out_f32 && !d.out_bf16 && !d.out_op && !d.out_u8 && d.act == FRIDO_ACT_NONE && !d.row_bias && !d.geglu &&
+                              !d.up2_phase && d.ldo == d.N && (d.N & 7) == 0 && !(d.residual && d.res_bf16),
+                          "sk_mode 2: plain f32 output [M][N] whose epilogue splitk_reduce8 could run (see frido_hip.h)");
+        }
     }
     if (const int arc = ensure_device_attrs()) return arc;
     const int tile = d.tile ? d.tile : pick_tile(d);

@@ -474,6 +474,56 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const FridoGnApply d, int 
 // denoiser forward; on the 16x16 and 8x8 planes those launches are pure latency (7-9 us each for a few hundred KB).
 // f32 slices: x + gamma + beta of 4 vectors = 96 VGPRs (3 vectors in the 1024-thread form, whose waves get 128 registers); larger
 // slices take more threads per workgroup instead of more registers per lane
+// x1 from the raw split-K partial sums of its producer (FridoGnApply.sk_*): splitk_reduce8_kernel's arithmetic, expression for
+// expression (slices added in ascending order from 0.f, then alpha * sum + (bias + rowvec), then the residual), so the value is
+// bit-identical to what the reduce launch would have stored; INFL slices' loads in flight per lane (the 1024-thread form has 128 registers: 4)
+template <int INFL>
+__device__ __forceinline__ void sk_finish8(const FridoGnApply& d, int64_t m, int c, int vstep, float (&v)[8]) {
+    const int64_t plane = (int64_t)d.B * d.HW * d.C1;
+    const float* w = d.sk_ws + m * d.C1 + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int z0 = 0; z0 < d.sk_n; z0 += INFL) {
+        float4 a[INFL], b[INFL];
+#pragma unroll
+        for (int u = 0; u < INFL; ++u)
+            if (z0 + u < d.sk_n) {
+                a[u] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane);
+                b[u] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane + 4);
+            }
+#pragma unroll
+        for (int u = 0; u < INFL; ++u)
+            if (z0 + u < d.sk_n) {
+                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+            }
+    }
+    float add[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) add[e] = 0.f;
+    if (d.sk_bias) {
+        const float4 a = *reinterpret_cast<const float4*>(d.sk_bias + c), b = *reinterpret_cast<const float4*>(d.sk_bias + c + 4);
+        add[0] += a.x; add[1] += a.y; add[2] += a.z; add[3] += a.w; add[4] += b.x; add[5] += b.y; add[6] += b.z; add[7] += b.w;
+    }
+    if (d.sk_rowvec) {
+        const float* rp = d.sk_rowvec + (int64_t)((int)m / d.sk_rows_per_vec + vstep) * d.sk_ldv + c;
+        const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
+        add[0] += a.x; add[1] += a.y; add[2] += a.z; add[3] += a.w; add[4] += b.x; add[5] += b.y; add[6] += b.z; add[7] += b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * d.sk_alpha + add[e];
+    if (d.sk_residual) {
+        const float* rp = d.sk_residual + m * d.sk_ldr + c;
+        const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (d.sk_out) {
+        float* o = d.sk_out + m * d.C1 + c;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 template <int NT, int GNF32_MAXV>
 __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, int Cc) {
     __shared__ double s_red[NT / 64][8];
@@ -498,9 +548,18 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
     float cs[8], cq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+    const bool from_sk = d.sk_ws != nullptr && c < d.C1;       // this lane's channels come from a split-K producer's partial sums
+    int sk_vstep = 0;
+    if (from_sk && d.sk_rowvec && d.sk_rowvec_step) sk_vstep = *d.sk_rowvec_step;
 #pragma unroll
     for (int k = 0; k < GNF32_MAXV; ++k) {
         const int p = pl + k * ppi;
+        if (from_sk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[k][e] = 0.f;
+            if (live && p < d.HW) sk_finish8<(NT == 1024 ? 4 : 8)>(d, (int64_t)b * d.HW + p, c, sk_vstep, xv[k]);
+            continue;
+        }
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bq = a;
         if (live && p < d.HW) {
             a = *reinterpret_cast<const float4*>(src + (int64_t)p * ldx);
@@ -778,6 +837,7 @@ extern "C" int frido_gn_stats(const FridoGnStats* d, frido_stream_t s) {
 
 extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->x1 && d->partials && d->weight && d->bias, "null pointer");
+    FRIDO_REQUIRE(!d->sk_ws, "sk_ws (x1 from split-K partial sums) is served by frido_gn_fused only");
     const int C = d->C1 + d->C2;
     FRIDO_REQUIRE(d->groups > 0 && d->groups <= 32 && C % d->groups == 0, "channels not divisible by groups (<= 32 groups)");
     FRIDO_REQUIRE((d->C1 & 3) == 0 && (d->C2 & 3) == 0, "channel counts must be multiples of 4");
@@ -822,7 +882,12 @@ extern "C" int frido_gn_fused(const FridoGnApply* d, frido_stream_t s) {
     int nt = 0;
     const int Cc = frido_gn_fused_chunk(d, &nt);
     FRIDO_REQUIRE(Cc > 0, "GroupNorm does not qualify for the one-launch kernel (use gn_stats + gn_apply)");
+    FRIDO_REQUIRE(!d->sk_ws || (!d->x_bf16 && d->sk_n > 1 && (d->C1 & 7) == 0 && (d->sk_ldr & 3) == 0 && (d->sk_ldv & 3) == 0 &&
+                                (!d->sk_rowvec || d->sk_rows_per_vec > 0) && (int64_t)d->B * d->HW < (1ll << 31)),
+                  "sk_ws (x1 from split-K partial sums): f32 input, >= 2 slices, C1 % 8 == 0, 4-element aligned strides");
     const int C = d->C1 + d->C2;
+    // (an sk_ws launch keeps the workgroup width of the plain one: the statistics' summation order, and with it every output bit, is
+    //  the same whether the reduction was deferred or not -- a 1024-thread form for them measured -2 us per launch and was not kept)
     if (d->x_bf16) hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
     else if (nt == 256) hipLaunchKernelGGL((gn_fused_f32_kernel<256, 4>), dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
     else if (nt == 512) hipLaunchKernelGGL((gn_fused_f32_kernel<512, 4>), dim3(C / Cc, d->B), dim3(512), 0, (hipStream_t)s, *d, Cc);

@@ -187,14 +187,14 @@ class UNetStagePlan:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def _norm(self, x1, x2, HW, name, eps, act, want_raw=False):
+    def _norm(self, x1, x2, HW, name, eps, act, want_raw=False, x1_dead=False):
         """GroupNorm32 / Normalize, SPADE-wrapped when the config says so (pyunet.py:209,233; attention.py:260)."""
         b = self.b
         if self.a.use_spade:
             g, be = self.spade.get(name, (None, None))
             return b.groupnorm(x1, x2, self.Bx, HW, name + ".param_free_norm", eps, gamma=g, beta=be, act=act,
-                               want_raw=want_raw)
-        return b.groupnorm(x1, x2, self.Bx, HW, name, eps, act=act, want_raw=want_raw)
+                               want_raw=want_raw, x1_dead=x1_dead)
+        return b.groupnorm(x1, x2, self.Bx, HW, name, eps, act=act, want_raw=want_raw, x1_dead=x1_dead)
 
     def _rowvec(self, ridx):
         d = dict(ptr=self.E.data_ptr() + 4 * int(self.res_off[ridx]), ld=int(self.res_off[-1]))
@@ -243,7 +243,7 @@ class UNetStagePlan:
         a1, raw = self._norm(x1, x2, HW, pre + ".in_layers.0", 1e-5, ACT_SILU, want_raw=has_skip)
         hmid = b.conv(a1, self.Bx, h, w, pre + ".in_layers.2", rowvec=rv)
         a1.free()
-        a2, _ = self._norm(hmid, None, HW, pre + ".out_layers.0", 1e-5, ACT_SILU)
+        a2, _ = self._norm(hmid, None, HW, pre + ".out_layers.0", 1e-5, ACT_SILU, x1_dead=True)     # hmid feeds this norm only
         hmid.free()
         if has_skip and raw.K % 64 == 0 and a2.K % 64 == 0:
             out = b.conv_plus_skip(a2, raw, self.Bx, h, w, pre + ".out_layers.3", pre + ".skip_connection")

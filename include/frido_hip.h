@@ -37,8 +37,10 @@ typedef uint16_t frido_bf16;
  * 1: rounds 1-2.  2: FridoGemm.sk_mode / gn_part inserted mid-struct, FridoAttnSmall / FridoSoftmax / FridoGnStats grew, the
  * split-K workspace starts with a 64-KiB ticket header that the CALLER zeroes once (frido_gemm_workspace_bytes), two-plane
  * operands became fp16 pairs (frido_x3_plane_format() == 1).  3 (r04): FridoGemm grew at its END (out_u8 / ldu8 / u8_mode, the fused
- * GroupNorm-apply input gn_*), two-plane operand producers saturate at +-65504. */
-#define FRIDO_ABI_VERSION 3
+ * GroupNorm-apply input gn_*), two-plane operand producers saturate at +-65504.  4 (r04): FridoGemm.sk_mode 2 + FridoGnApply.sk_* at the
+ * struct's END (a split-K GEMM's reduction finished by the GroupNorm launch that consumes its output). */
+#define FRIDO_ABI_VERSION 4
+#define FRIDO_SPLITK_HEADER_BYTES 65536     /* the ticket header at the start of a split-K workspace; partial sums follow: [splitk][M][N] f32 */
 
 #define FRIDO_OK 0
 #define FRIDO_EINVAL (-1)
@@ -108,7 +110,11 @@ typedef struct FridoGemm {
                                    1 = the LAST workgroup of each output tile to arrive (ticket per tile, agent-scope release /
                                    acquire around it; partials stored fragment-major per tile), which then runs the GEMM's own
                                    epilogue -- no second launch, and gn_part stays available.  Ring kernels only (the bf16
-                                   patch-staged 3x3 kernel always uses 0); at most 16384 output tiles. */
+                                   patch-staged 3x3 kernel always uses 0); at most 16384 output tiles.
+                                   2 (r04) = NOBODY in this launch: the [splitk][M][N] partials stay in `ws` and the epilogue
+                                   (alpha, bias, rowvec, residual, out_f32) is the CONSUMER's job -- a frido_gn_fused launch with
+                                   FridoGnApply.sk_* set, issued before anything else touches the workspace.  Ring kernels only;
+                                   f32 output [M][N] (ldo == N), no activation / row bias / GEGLU / operand output. */
     float* gn_part;             /* optional (bf16x3 f32-stream outputs): per-channel partial {sum, sum of squares} of the STORED values
                                    over every 32-row block, gn_part[((m / 32) * N + n) * 2 + {0, 1}], written by the store-from-
                                    registers epilogue; frido_gn_stats (p1 / p2) turns them into GroupNorm statistics without
@@ -180,6 +186,17 @@ typedef struct FridoGnApply {
     float* out_f32;
     int32_t x_bf16;             /* 1: x1 / x2 are bf16 */
     int32_t gb_bf16;            /* 1: gamma / beta are bf16 */
+    /* optional (r04, ABI 4), frido_gn_fused with f32 input only: x1 is not READ but produced here, from the raw split-K partial sums
+       of the GEMM that would have written it (FridoGemm.sk_mode 2 leaves them in its workspace and launches no reduction):
+         x1[m][c] = sk_alpha * sum_z sk_ws[z][m][c] (z = 0 .. sk_n - 1 in order) + sk_bias[c] + sk_rowvec[m / sk_rows_per_vec + *sk_rowvec_step][c]
+                    + sk_residual[m][c]
+       -- splitk_reduce's arithmetic bit for bit -- with m = b * HW + pixel, rows C1 wide.  The value is also stored to sk_out[m][c]
+       (row stride C1) unless sk_out is NULL (nobody else reads the tensor).  sk_ws = workspace + FRIDO_SPLITK_HEADER_BYTES.
+       One launch and one round trip of the tensor less per small-plane convolution (pyunet.py:262-300: conv -> GroupNorm). */
+    const float* sk_ws; int32_t sk_n; float sk_alpha;
+    const float* sk_bias; const float* sk_rowvec; const int32_t* sk_rowvec_step; int32_t sk_rows_per_vec, sk_ldv;
+    const float* sk_residual; int32_t sk_ldr;
+    float* sk_out;
 } FridoGnApply;
 
 /* LayerNorm over the last dim (eps 1e-5, affine): attention.py:203-205 -> operand tensor. */

@@ -977,6 +977,99 @@ def test_gn_conv_fused(case):
         assert _relerr(parts[:, :, 0], blocks.sum(1)) < 1e-5 and _relerr(parts[:, :, 1], (blocks ** 2).sum(1)) < 1e-5
 
 
+@pytest.mark.parametrize("W,C1,C2,Cout_prev,splitk,spade,resid,dead", [(16, 576, 0, 576, 4, False, False, False), (8, 960, 0, 960, 8, True, True, False),
+                                                                       (16, 384, 192, 384, 3, False, True, False), (8, 960, 0, 960, 5, False, False, True)])
+def test_splitk_reduction_deferred_into_groupnorm(W, C1, C2, Cout_prev, splitk, spade, resid, dead):
+    """r04 (FridoGemm.sk_mode 2 + FridoGnApply.sk_*): a split-K conv whose output goes straight into a one-launch GroupNorm leaves its
+    reduction + epilogue (bias, timestep vector, residual) to that launch.  Everything the pair produces -- the conv output, the
+    normalised operand, the raw operand copy -- must equal the conv -> splitk_reduce -> GroupNorm chain BIT FOR BIT, and fp32 torch."""
+    import frido_amd.builder as bld
+    from frido_amd import tune, _lib
+    from frido_amd.builder import ACT_SILU
+    B, H, Cin = 16, W, 64
+    HW, M, C = H * W, 16 * W * W, C1 + C2
+    xin = _t("sd:x", B, Cin, H, W)
+    wc, bc = _t("sd:wc", C1, Cin, 3, 3) / np.sqrt(9 * Cin), _t("sd:bc", C1)
+    w, bi = 1 + 0.1 * _t("sd:gw", C), 0.1 * _t("sd:gb", C)
+    x2 = _t("sd:x2", B, HW, C2) * 0.7 if C2 else None
+    gam, bet = (0.3 * _t("sd:gg", B, HW, C), 0.3 * _t("sd:gbt", B, HW, C)) if spade else (None, None)
+    res = _t("sd:res", M, C1) if resid else None
+    tvec = _t("sd:tv", 3, C1)
+    weights = {"n.weight": w.cuda(), "n.bias": bi.cuda(), "c.weight": wc.cuda(), "c.bias": bc.cuda()}
+    outs = {}
+    for defer in (True, False):
+        b = _builder(2, weights)
+        xd = xin.cuda()
+        a_in = b.pack(xd.data_ptr(), B, HW, Cin, 0, Cin, nchw=True)
+        f2 = None
+        if C2:
+            f2 = b.f32(M, C2)
+            f2.view().copy_(x2.view(M, C2).cuda())
+        g = be = None
+        if spade:
+            g, be = b.f32(M, C), b.f32(M, C)
+            g.view().copy_(gam.view(M, C).cuda())
+            be.view().copy_(bet.view(M, C).cuda())
+        r = None
+        if resid:
+            r = b.f32(M, C1)
+            r.view().copy_(res.cuda())
+        tv = tvec.cuda()
+        step = torch.tensor([2], dtype=torch.int32, device="cuda")
+        rv = dict(ptr=tv.data_ptr(), ld=C1, rows_per_vec=1 << 30, step=step.data_ptr())
+        was = tune.ENABLED
+        tune.ENABLED = False
+        f1 = b.conv(a_in, B, H, W, "c", rowvec=rv, residual=r)
+        tune.ENABLED = was
+        st = b.prog.ops[-1][1]                      # force the split the tuner picks on these planes
+        st.tile, st.splitk, st.sk_mode, st.gn_part = 7, splitk, 0, None
+        st.ws = tune.workspace_for(st, b.device)
+        b.prog._packed = None
+        f1.view().fill_(float("nan"))              # whoever finishes the reduction must write every element
+        bld.SK_DEFER = defer
+        try:
+            a, raw = b.groupnorm(f1, f2, B, HW, "n", 1e-5, gamma=g, beta=be, act=ACT_SILU, want_raw=True, x1_dead=dead)
+        finally:
+            bld.SK_DEFER = True
+        kinds = [k for k, _ in b.prog.ops]
+        assert kinds[-1] == _lib.OP_KINDS["FRIDO_OP_GN_FUSED"]
+        assert st.sk_mode == (2 if defer else 0) and bool(b.prog.ops[-1][1].sk_ws) == defer
+        _run(b)
+        outs[defer] = (f1.view().clone(), a.to_f32().clone(), raw.to_f32().clone())
+    x_def, a_def, raw_def = outs[True]
+    x_ref, a_ref, raw_ref = outs[False]
+    assert torch.isfinite(x_ref).all()
+    if dead:
+        assert torch.isnan(x_def).all()             # nobody reads the tensor: it is not materialised
+    else:
+        assert torch.equal(x_def, x_ref)
+    assert torch.equal(a_def, a_ref) and torch.equal(raw_def, raw_ref)
+    ref = F.conv2d(xin, wc, bc, padding=1).permute(0, 2, 3, 1).reshape(M, C1) + tvec[2]
+    if resid:
+        ref = ref + res
+    assert _relerr(x_ref.cpu(), ref) < 2e-5
+    xc = ref.view(B, HW, C1) if x2 is None else torch.cat([ref.view(B, HW, C1), x2], dim=-1)
+    y = F.group_norm(xc.permute(0, 2, 1).reshape(B, C, H, W), 32, w, bi, 1e-5)
+    if spade:
+        y = y * (1 + gam.permute(0, 2, 1).reshape(B, C, H, W)) + bet.permute(0, 2, 1).reshape(B, C, H, W)
+    assert _relerr(a_def.cpu(), F.silu(y).permute(0, 2, 3, 1).reshape(M, C)) < 2e-5
+
+
+def test_splitk_deferral_is_rejected_where_nobody_could_finish_it():
+    import ctypes as C_
+    from frido_amd import _lib
+    dummy = torch.zeros(1 << 20, device="cuda")
+    kind, st = _lib.make_op("FRIDO_OP_GEMM", M=1024, N=192, K=1024, batch=1, nsplit=2, lda=1024, ldb=1024, tile=3, splitk=4, sk_mode=2,
+                            A=dummy.data_ptr(), B=dummy.data_ptr(), ws=dummy.data_ptr(), out_f32=dummy.data_ptr(), ldo=200)
+    assert _lib.lib().frido_gemm(C_.addressof(st), None) == -1 and b"sk_mode 2" in _lib.lib().frido_last_error()      # strided output
+    st.ldo, st.act = 192, 2
+    assert _lib.lib().frido_gemm(C_.addressof(st), None) == -1                                                          # activation
+    kind, gn = _lib.make_op("FRIDO_OP_GN_APPLY", x1=dummy.data_ptr(), C1=64, B=1, HW=64, groups=32, nsplit_px=1, partials=dummy.data_ptr(),
+                            weight=dummy.data_ptr(), bias=dummy.data_ptr(), nsplit=2, out_op=dummy.data_ptr(), out_lo=4096,
+                            sk_ws=dummy.data_ptr(), sk_n=2)
+    assert _lib.lib().frido_gn_apply(C_.addressof(gn), None) == -1 and b"frido_gn_fused only" in _lib.lib().frido_last_error()
+
+
 def test_gn_conv_rejects_what_it_cannot_run():
     import ctypes as C_
     from frido_amd import _lib

@@ -35,8 +35,9 @@ def rand_op(b, rows, K):
     return b.pack(x.data_ptr(), 1, rows, K, 0, K)
 
 
-def attn(Nq, Nk, d, self_attn):
-    b = Builder(DEV, 2, {})
+def attn(Nq, Nk, d, self_attn, fused_ln=False):
+    """fused_ln: the launch as the sampler issues its cross-attention -- the LayerNorm of the result and an operand copy from the same kernel"""
+    b = Builder(DEV, 2, {"ln.weight": torch.ones(d, device=DEV), "ln.bias": torch.zeros(d, device=DEV)})
     q = rand_op(b, B * Nq, d)
     k = q if self_attn else rand_op(b, B * Nk, d)
     Np = (Nk + 31) // 32 * 32
@@ -51,11 +52,11 @@ def attn(Nq, Nk, d, self_attn):
     torch.cuda.synchronize()
     b.prog.ops.clear()
     b.prog._packed = None
-    b.attention(q, d, k, d, vT, B, Nq, Nk, d, residual=res, stream=True)
+    b.attention(q, d, k, d, vT, B, Nq, Nk, d, residual=res, stream=True, **(dict(also_op=True, ln=("ln", 1e-5)) if fused_ln else {}))
     kinds = [op[0] for op in b.prog.ops]
     us = timed(b)
     fl = 4.0 * B * Nq * Nk * d
-    print(f"attention Nq={Nq} Nk={Nk} d={d}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s algorithmic  ops {kinds}")
+    print(f"attention Nq={Nq} Nk={Nk} d={d}{' +ln +op' if fused_ln else ''}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s algorithmic  ops {kinds}")
 
 
 if __name__ == "__main__":
@@ -65,3 +66,6 @@ if __name__ == "__main__":
     attn(64, 77, 960, False)
     attn(256, 256, 576, True)
     attn(64, 64, 960, True)
+    for shp in ((1024, 26, 384), (256, 26, 576), (64, 26, 960)):      # config 2: 26 layout tokens
+        attn(*shp, False)
+        attn(*shp, False, fused_ln=True)

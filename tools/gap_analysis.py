@@ -30,8 +30,8 @@ def main():
     end = max(i for i, r in enumerate(rows) if own(r[2]))
     rows = rows[:end + 1]
     cur = rows[0][1]
-    for i, (s0, e0, _) in enumerate(rows):
-        if i > 1000 and s0 - cur > 5_000_000:          # first host round trip after the pass
+    for i, (s0, e0, nm) in enumerate(rows):
+        if i > 1000 and s0 - cur > 5_000_000 and not own(nm):      # first host round trip INTO torch code after the pass: the checks
             rows = rows[:i]
             break
         cur = max(cur, e0)
@@ -63,7 +63,7 @@ def main():
     out = {"kernels": len(rows), "wall_ms": wall / 1e6, "busy_ms": busy / 1e6, "idle_ms": (wall - busy) / 1e6,
            "idle_frac": (wall - busy) / wall, "sum_dur_ms": sum(e - s for s, e, _ in rows) / 1e6,
            "gap_us_median": gaps[len(gaps) // 2] / 1e3 if gaps else 0, "gap_us_p90": gaps[int(len(gaps) * .9)] / 1e3 if gaps else 0,
-           "n_gaps": len(gaps),
+           "n_gaps": len(gaps), "gaps_gt_5ms": [round(g / 1e6, 2) for g in gaps if g > 5_000_000],
            "bubbles_gt2us_by_preceding_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(before.items(), key=lambda kv: -kv[1][1])[:8]},
            "bubbles_gt2us_by_following_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(after.items(), key=lambda kv: -kv[1][1])[:8]},
            "per_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}}

@@ -30,10 +30,10 @@ def table(prog, sp, title, top=None):
         desc, fl = "", 0.0
         if n == "GEMM":
             fl = 2.0 * st.M * st.N * (st.K + st.K2) * st.batch
-            desc = f"M={st.M} N={st.N} K={st.K}+{st.K2} b={st.batch} {'conv%dx%d s%d u%d d%d' % (st.kh, st.kw, st.stride, st.up_shift, st.dn_shift) if st.conv else 'dense'} t{st.tile}" + (" gn" + ("+spade" if st.gn_gamma else "") if st.gn_x1 else "")
+            desc = f"M={st.M} N={st.N} K={st.K}+{st.K2} b={st.batch} {'conv%dx%d s%d u%d d%d' % (st.kh, st.kw, st.stride, st.up_shift, st.dn_shift) if st.conv else 'dense'} t{st.tile}" + (" gn" + ("+spade" if st.gn_gamma else "") if st.gn_x1 else "") + (f" sk{st.splitk}" + ("->gn" if st.sk_mode == 2 else "") if st.splitk > 1 else "")
             n = "GEMM-conv" if st.conv else "GEMM"
         if n in ("GN_APPLY", "GN_STATS", "GN_FUSED"):
-            desc = f"B={st.B} HW={st.HW} C={st.C1 + st.C2} S={st.nsplit_px}" + (" spade" if n in ("GN_APPLY", "GN_FUSED") and st.gamma else "")
+            desc = f"B={st.B} HW={st.HW} C={st.C1 + st.C2} S={st.nsplit_px}" + (" spade" if n in ("GN_APPLY", "GN_FUSED") and st.gamma else "") + (f" <-sk{st.sk_n}" if n == "GN_FUSED" and st.sk_ws else "")
         if n == "LAYERNORM":
             desc = f"rows={st.rows} C={st.C}"
         if n in ("ATTN_SMALL", "ATTN_FLASH"):
