@@ -31,7 +31,10 @@ __device__ __forceinline__ f32x4 mma(const bf16x8 (&a)[2], const bf16x8 (&b)[2],
 // workgroup shorten the serial load -> MFMA chain), NF = compile-time bound on the 16-key score fragments (Nk <= 16 NF).
 template <int NS, int NW, int NF>
 __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmall d) {
-    constexpr int G = NW == 16 ? 2 : 4;                 // output fragments per LDS transpose group
+    // output fragments per LDS transpose group.  r04: 2 as well for the four-wave short-key form (<= 32 keys, the cross-attention of the
+    // 32 x 32 plane): its static LDS drops from 20 to 12 KB, so with the 25-KB row buffer of the fused LayerNorm FOUR workgroups fit a
+    // CU instead of three and the launch's 1024 workgroups are all resident at once
+    constexpr int G = (NW == 16 || (NW == 4 && NF == 2)) ? 2 : 4;
     constexpr int SP_LD = NF * 16 + 4, SO_LD = G * 16 + 4, P_LD = NF * 16 + 8;   // P rows: 16-byte aligned fragment reads
     constexpr int SLD = SP_LD > SO_LD ? SP_LD : SO_LD;
     __shared__ __attribute__((aligned(16))) float s_part[NW * 16 * SLD];          // phase 1/2 partial scores; phase 3 slabs
