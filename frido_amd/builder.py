@@ -33,6 +33,7 @@ GN_CONV = os.environ.get("FRIDO_GN_CONV", "1")
 # gn_fused + the split-K ring conv) and -2.3 % end to end (profiles/r04_gnconv_splitk_ab.txt: few chunks per slice leave the prologue's
 # un-overlapped staging and the 196-KB partial-sum epilogue uncovered), so it stays OFF; the C ABI keeps the option (FridoGemm.splitk on tiles 20 / 21)
 GN_CONV_SPLITK = os.environ.get("FRIDO_GN_CONV_SPLITK", "0") != "0"
+ATTN_SKIP_DEAD_STREAM = os.environ.get("FRIDO_ATTN_SKIP_DEAD_STREAM", "1") != "0"      # r05: cross-attention does not store f32 rows nobody reads (A/B switch)
 GN_CONV_PREFER = int(os.environ.get("FRIDO_GN_CONV_PREFER", "256"))      # A/B: which tile height is tried first where both fill the chip
 
 
@@ -478,7 +479,9 @@ class Builder:
             return {}
         if (st.out_f32 != x1.ptr or st.M != M or st.N != x1.C or st.ldo != st.N or st.N % 8 or st.batch != 1 or st.act or st.geglu
                 or st.row_bias or st.out_op or st.out_u8 or st.out_bf16 or st.up2_phase or (st.residual and st.res_bf16)
-                or (st.rowvec and st.rows_per_vec <= 0)):
+                or (st.rowvec and (st.rows_per_vec <= 0 or st.ldv % 8)) or (st.residual and st.ldr % 8)):
+            # (r05, advisor: ldv / ldr % 8 -- sk_finish8 mirrors splitk_reduce8, the vec8 form launch_splitk_reduce takes only for
+            #  8-element aligned strides; anything else keeps its reduce launch)
             return {}
         st.sk_mode = 2
         self.prog._packed = None
@@ -557,13 +560,15 @@ class Builder:
 
     # ---- attention (single head, unfused: QK^T -> softmax -> PV on the MFMA GEMM) -----------------
     def attention(self, q, ldq, k, ldk, vT, B, Nq, Nk, d, *, q_off=0, k_off=0, bias_ptr=None, residual=None, stream=False,
-                  also_op=False, ln=None):
+                  also_op=False, ln=None, stream_dead=False):
         """q: operand rows [B*Nq] (row stride ldq, column offset q_off), k: operand rows [B*Nk], vT: operand
         [B][d][Nk_pad] (zero beyond Nk).  Returns operand O [B*Nq][d].  scale = d ** -0.5 (attention.py:158).
         stream=True (the out projection is folded into vT): returns the residual-stream activation O + bias + residual.
         ln=(weight name, eps) with stream=True in bf16x3 mode: where the kernel's workgroups own whole rows (flash kernel with
         d = 256 / 384, short-key kernel with >= 256 workgroups) the LayerNorm of the result comes back as the operand `res.ln_copy`
-        from the same launch; otherwise the attribute is absent and the caller runs layernorm()."""
+        from the same launch; otherwise the attribute is absent and the caller runs layernorm().
+        stream_dead=True (r05): the caller reads ONLY res.op_copy / res.ln_copy; when the launch produces both, the f32 stream rows
+        are not stored (res.stream_skipped = True) -- 20 % of the launch's bytes on the 32 x 32 plane."""
         Np = rup(Nk, 32)
         aligned = ldq % 8 == 0 and ldk % 8 == 0 and q_off % 8 == 0 and k_off % 8 == 0
         small = Nk <= 128 and Nq % 16 == 0 and d % 32 == 0 and aligned
@@ -590,6 +595,10 @@ class Builder:
                     o = self.op(B * Nq, d)
                     kw.update(out_op=o.ptr, out_lo=o.lo, ldo=d)
                     res.op_copy = o
+                if (stream_dead and ATTN_SKIP_DEAD_STREAM and small and getattr(res, "op_copy", None) is not None
+                        and getattr(res, "ln_copy", None) is not None):
+                    kw["skip_act_store"] = 1
+                    res.stream_skipped = True
                 self.prog.emit(kind, out_act=res.ptr, ld_act=d, residual=residual.ptr if residual is not None else None,
                                ldr=residual.C if residual is not None else 0, bias=bias_ptr, act_bf16=int(res.bf16), **kw)
                 return res

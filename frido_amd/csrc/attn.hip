@@ -35,7 +35,12 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     // 32 x 32 plane): its static LDS drops from 20 to 12 KB, so with the 25-KB row buffer of the fused LayerNorm FOUR workgroups fit a
     // CU instead of three and the launch's 1024 workgroups are all resident at once
     constexpr int G = (NW == 16 || (NW == 4 && NF == 2)) ? 2 : 4;
-    constexpr int SP_LD = NF * 16 + 4, SO_LD = G * 16 + 4, P_LD = NF * 16 + 8;   // P rows: 16-byte aligned fragment reads
+    // (r05) transpose slabs.  G = 4: rows of 68 floats, the 16-byte read-back (lane -> row lane/4, 16 columns) is conflict-free as it is.
+    // G = 2 (32 columns per row, 8 per lane): with 36-float rows the ds_read_b128 lane groups {rows 0,3,5,6} / {1,2,4,7} met on the
+    // same banks two ways (PMC r04: 25 % of the kernel's LDS cycles were conflict cycles); rows of 48 floats with the 4-float chunk
+    // index XORed by (row & 7) give every lane group 16 distinct 4-bank spans, and the b32 slab stores stay conflict-free
+    constexpr int SP_LD = NF * 16 + 4, SO_LD = G == 2 ? 48 : G * 16 + 4, P_LD = NF * 16 + 8;   // P rows: 16-byte aligned fragment reads
+    constexpr bool SO_SWZ = G == 2;
     constexpr int SLD = SP_LD > SO_LD ? SP_LD : SO_LD;
     __shared__ __attribute__((aligned(16))) float s_part[NW * 16 * SLD];          // phase 1/2 partial scores; phase 3 slabs
     __shared__ __attribute__((aligned(16))) frido_bf16 s_p[NS * 16 * P_LD];
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
             sum += v[h];
         }
         const float inv = 1.0f / wave_sum(sum);
+        status_raise(false, lane == 0 && stat_bad(mx, inv));
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const int c = lane + h * 64;
@@ -158,6 +164,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     float* so = s_part + wave * 16 * SO_LD;         // this wave's transpose slab (the partial scores are dead by now)
     constexpr int CPL = G * 4;                      // columns per lane on the read-back: 16 rows x 4 lanes
     const int orow = lane >> 2, oc = (lane & 3) * CPL;
+    bool sat = false;                              // an operand value beyond the fp16 planes' range (common.h status word)
     float ln_s = 0.f, ln_q = 0.f;                  // LayerNorm of the stream rows (ln_op): this lane's share of its row's sum / sum of squares
     // ... and the values themselves, parked in (dynamic) LDS at [row][dv + 4]: every lane reads back only what it wrote itself, so the
     // second pass needs no barrier -- and no round trip through the stores it has just issued (re-reading out_act cost ~15 us a launch)
@@ -187,18 +194,19 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
         for (int q = 0; q < G; ++q)
             if (q < ng) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) so[(g * 4 + e) * SO_LD + q * 16 + r] = acc[q][e];
+                for (int e = 0; e < 4; ++e) so[(g * 4 + e) * SO_LD + ((q * 16 + r) ^ (SO_SWZ ? ((g * 4 + e) & 7) << 2 : 0))] = acc[q][e];
             }
         // transposed read-back: lane -> row lane/4, CPL consecutive columns, 16-byte accesses
         if (oc < ng * 16) {
-            const float* src = so + orow * SO_LD + oc;
+            const float* srow = so + orow * SO_LD;
+            const int sxor = SO_SWZ ? (orow & 7) << 2 : 0;      // 4-float chunk c of this row lives at chunk c ^ (row & 7)
             const int col = tb * 16 + oc;
             if (d.out_act) {                    // residual-stream form: O + bias + residual
                 const int64_t ro = (int64_t)(row0 + orow) * d.ldr + col, oo = (int64_t)(row0 + orow) * d.ld_act + col;
                 float keep[CPL];                // (r03) the same values once more as an operand, when out_op is given as well
 #pragma unroll
                 for (int i = 0; i < CPL / 4; ++i) {
-                    float4 v = make_float4(src[i * 4], src[i * 4 + 1], src[i * 4 + 2], src[i * 4 + 3]);
+                    float4 v = *reinterpret_cast<const float4*>(srow + ((oc + i * 4) ^ sxor));
                     if (d.bias) {
                         const float4 bb = *reinterpret_cast<const float4*>(d.bias + col + i * 4);
                         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -207,7 +215,9 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                         const float4 rr = load_act4(d.residual, ro + i * 4, d.act_bf16);
                         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                     }
-                    if (d.act_bf16) {
+                    if (d.skip_act_store) {
+                        // (r05) nobody reads the f32 stream rows: the operand copy and / or the fused LayerNorm are the only consumers
+                    } else if (d.act_bf16) {
                         *reinterpret_cast<uint2*>(reinterpret_cast<frido_bf16*>(d.out_act) + oo + i * 4) =
                             make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
                     } else {
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                         uint32_t h[8], l[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) split_op(keep[i * 8 + e], NS, h[e], l[e]);
+                        if (NS == 2) sat |= op_sat8(keep + i * 8);
                         *reinterpret_cast<uint4*>(dst + i * 8) =
                             make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                         if (NS == 2)
@@ -238,8 +249,11 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
 #pragma unroll
                 for (int i = 0; i < CPL / 8; ++i) {
                     uint32_t h[8], l[8];
+                    const float4 s0 = *reinterpret_cast<const float4*>(srow + ((oc + i * 8) ^ sxor)), s1 = *reinterpret_cast<const float4*>(srow + ((oc + i * 8 + 4) ^ sxor));
+                    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) split_op(src[i * 8 + e], NS, h[e], l[e]);
+                    for (int e = 0; e < 8; ++e) split_op(sv[e], NS, h[e], l[e]);
+                    if (NS == 2) sat |= op_sat8(sv);
                     *reinterpret_cast<uint4*>(dst + i * 8) =
                         make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                     if (NS == 2)
@@ -281,6 +295,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
 #pragma unroll
         for (int w = 0; w < NW; ++w) Q += s_part[(w * 16 + orow) * 2 + 1];
         const float rstd = 1.0f / sqrtf(Q / d.dv + d.ln_eps);
+        status_raise(false, wave == 0 && (lane & 3) == 0 && stat_bad(mean, rstd));
         // second pass over the values this lane parked in LDS
         const float* xr = s_rows + orow * ldrow;
         frido_bf16* dst = d.ln_op + (int64_t)(row0 + orow) * d.ld_ln;
@@ -300,11 +315,13 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                 uint32_t h[8], l[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) split_op(y[e], NS, h[e], l[e]);
+                sat |= op_sat8(y);
                 *reinterpret_cast<uint4*>(dst + c) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 *reinterpret_cast<uint4*>(dst + d.ln_lo + c) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
         }
     }
+    status_raise(sat);
 }
 
 // static + dynamic LDS of the LayerNorm form can pass 64 KiB (eight score fragments, d >= 384): per-device opt-in, set once
@@ -360,6 +377,7 @@ extern "C" int frido_attn_small(const FridoAttnSmall* d, frido_stream_t s) {
                       (d->vt_lo & 7) == 0 && (d->out_lo & 7) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
                   "strides and plane offsets must keep 16-byte alignment");
     FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
+    FRIDO_REQUIRE(!d->skip_act_store || (d->out_act && (d->out_op || d->ln_op)), "skip_act_store: stream form with an operand copy and / or the fused LayerNorm as its consumers");
     FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && d->B * (d->Nq / 16) >= 256 && d->dv <= 1024 && d->ln_w && d->ln_b &&
                                 (d->ld_ln & 7) == 0 && (d->ln_lo & 7) == 0),
                   "ln_op: bf16x3 f32-stream output, B * Nq / 16 >= 256 (one workgroup per 16 rows owns them whole), weight and bias given");

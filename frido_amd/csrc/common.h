@@ -63,6 +63,52 @@ __device__ __forceinline__ void split_op(float v, int ns, uint32_t& hi, uint32_t
         lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
     }
 }
+// ---- sticky status word (r05).  The library cannot throw from a kernel; instead every operand producer and every normalisation
+//      kernel ORs a bit into a per-translation-unit device word when it meets a value the arithmetic cannot represent, and
+//      frido_status_flags() (runtime.hip) ORs the words together for the host:
+//        bit 0 (FRIDO_STATUS_SATURATED): a two-plane fp16 operand producer clamped a value at +-65504 (split_op's range) -- the
+//              product that consumes it is no longer fp32-class; such a model needs the bf16-pair planes;
+//        bit 1 (FRIDO_STATUS_NONFINITE): a GroupNorm / LayerNorm / softmax statistic was NaN or infinite -- a NaN / inf reached
+//              the residual stream (split_op's clamp turns a NaN OPERAND into a finite one, so this is where NaNs stay visible:
+//              every stream tensor of the path is normalised within a block or two).
+//      One word per .hip file (no -fgpu-rdc: device globals are not shared between translation units); each file registers an
+//      accessor with the runtime at load time.  The checks cost one v_max3 per two values and one compare per eight.
+namespace {
+__device__ unsigned g_frido_status_word = 0;
+}
+typedef int (*frido_status_accessor)(unsigned* word, int clear);
+void frido_register_status_word(frido_status_accessor fn);       // runtime.hip
+namespace {
+inline int frido_status_rw(unsigned* word, int clear) {
+    unsigned w = 0;
+    if (hipMemcpyFromSymbol(&w, HIP_SYMBOL(g_frido_status_word), sizeof(w), 0, hipMemcpyDeviceToHost) != hipSuccess) return FRIDO_EHIP;
+    if (clear && w) {
+        const unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_frido_status_word), &z, sizeof(z), 0, hipMemcpyHostToDevice) != hipSuccess) return FRIDO_EHIP;
+    }
+    *word = w;
+    return FRIDO_OK;
+}
+struct FridoStatusRegistrar {
+    FridoStatusRegistrar() { frido_register_status_word(&frido_status_rw); }
+};
+FridoStatusRegistrar g_frido_status_registrar;
+}  // namespace
+// |v| beyond the fp16 planes' range (false for NaN: see bit 1); the 8-value form is four v_max3_f32 and one compare
+__device__ __forceinline__ bool op_sat(float v) { return FRIDO_X3_F16 && fabsf(v) > 65504.0f; }
+__device__ __forceinline__ bool op_sat4(const float* v) {
+    return FRIDO_X3_F16 && fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.0f;
+}
+__device__ __forceinline__ bool op_sat8(const float* v) {
+    const float m0 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2])), m1 = fmaxf(fmaxf(fabsf(v[3]), fabsf(v[4])), fabsf(v[5]));
+    return FRIDO_X3_F16 && fmaxf(fmaxf(m0, m1), fmaxf(fabsf(v[6]), fabsf(v[7]))) > 65504.0f;
+}
+__device__ __forceinline__ bool stat_bad(float mean, float rstd) { return !(fabsf(mean) <= 3.0e38f) || !(rstd > 0.0f) || !(rstd <= 3.0e38f); }
+// at the end of a kernel (or of a thread's work): one atomic per lane that saw something, none otherwise
+__device__ __forceinline__ void status_raise(bool saturated, bool nonfinite = false) {
+    if (saturated || nonfinite) atomicOr(&g_frido_status_word, (saturated ? 1u : 0u) | (nonfinite ? 2u : 0u));
+}
+
 // one MFMA pass on operand fragments of an NS-plane operand format
 template <int NS>
 __device__ __forceinline__ f32x4 mfma_op(bf16x8 a, bf16x8 b, f32x4 c) {

@@ -79,7 +79,7 @@ __device__ __forceinline__ void wait_unit(CgUnit& u) {       // at most N younge
 // gn_apply_kernel's per-element arithmetic (norm.hip), expression for expression
 template <bool SPADE>
 __device__ __forceinline__ void cg_convert(const CgUnit& u, const float (&sc)[8], const float (&sh)[8], bool norm, bool silu, bool zero,
-                                           u32x4& hi, u32x4& lo) {
+                                           u32x4& hi, u32x4& lo, bool& sat) {
     const float xin[8] = {u.x0[0], u.x0[1], u.x0[2], u.x0[3], u.x1[0], u.x1[1], u.x1[2], u.x1[3]};
     float y[8];
 #pragma unroll
@@ -101,6 +101,7 @@ __device__ __forceinline__ void cg_convert(const CgUnit& u, const float (&sc)[8]
     uint32_t h[8], l[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) split_op(y[e], 2, h[e], l[e]);
+    sat |= op_sat8(y);       // (status word, common.h: 4 v_max3 + 1 compare per 8 values, the flag lives in an SGPR pair)
     hi = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
     lo = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
     if (zero) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             var = var < 0.0 ? 0.0 : var;
             s_mean[t] = (float)mean;
             s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
+            if (bid == 0) status_raise(false, stat_bad(s_mean[t], s_rstd[t]));      // (one workgroup per launch reports: tile 0 sees sample 0's statistics only -- gn_stats flags the others)
         }
         __syncthreads();
         for (int c = t; c < C; c += NT) {
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             u.b1 = gload128(bet + o + 4);
         }
     };
+    bool sat = false;                                 // an operand value beyond the fp16 planes' range was staged (common.h status word)
     const int psafe = img * HW + y0 * W;              // a valid pixel for lanes whose slot is halo / unused (loaded, never written)
     const bool do_silu = d.gn_act == FRIDO_ACT_SILU;
     auto stage_load = [&](auto rc, int c, CgUnit& u) {
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
         }
         u32x4 hi, lo;
-        cg_convert<SPADE>(u, sc, sh, true, do_silu, pix[r] < 0, hi, lo);
+        cg_convert<SPADE>(u, sc, sh, true, do_silu, pix[r] < 0, hi, lo, sat);
         if (pix[r] != -2) {
             const unsigned a = lds0 + (unsigned)((c & 1) * PBUF) + wslot + (unsigned)(r * 8192);
             lds_write128u(a, hi);
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         for (int q = 0; q < RU; ++q) {
             wait_unit<YOUNGER, false>(u[q]);
             u32x4 hi, lo;
-            cg_convert<false>(u[q], none, none, false, false, false, hi, lo);
+            cg_convert<false>(u[q], none, none, false, false, false, hi, lo, sat);
             const unsigned a = lds0 + (unsigned)(buf * PBUF) + wslot + (unsigned)(q * 8192);
             lds_write128u(a, hi);
             lds_write128u(a + PPLANE, lo);
@@ -469,6 +472,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         chunk(std::integral_constant<int, 1>{}, nc - 1);
     }
     wait_vmcnt<0>();
+    status_raise(sat);
     if constexpr (CG_ABLATE & 32) {       // (timing only) no epilogue: keep the accumulators live, store nothing
         float sink = 0.f;
         for (auto& ai : acc) for (auto& aj : ai) sink += aj[0] + aj[1] + aj[2] + aj[3];
@@ -490,7 +494,8 @@ bool convgn_ok(const FridoGemm& d, int bm) {
     const int R = bm / W;
     if ((R + 2) * (W + 2) > (bm == 256 ? 396 : 204)) return false;
     if ((d.gn_C1 & 31) || (d.gn_C2 & 31) || (d.gn_C2 && !d.gn_x2) || C != d.Cin || C > 960 || d.K != 9 * d.Cin) return false;
-    if (d.gn_groups <= 0 || d.gn_groups > 64 || C % d.gn_groups || d.gn_nsplit_px < 1 || d.gn_nsplit_px > 64) return false;
+    // (<= 32 groups: the statistics prologue is laid out for them, like gn_apply_kernel's)
+    if (d.gn_groups <= 0 || d.gn_groups > 32 || C % d.gn_groups || d.gn_nsplit_px < 1 || d.gn_nsplit_px > 64) return false;
     if ((d.gn_gamma == nullptr) != (d.gn_beta == nullptr)) return false;
     if (d.K2) {
         if (!d.raw_x1 || (d.raw_C1 & 31) || (d.raw_C2 & 31) || (d.raw_C2 && !d.raw_x2) || d.K2 != d.raw_C1 + d.raw_C2) return false;

@@ -362,6 +362,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
     //  kernel the extra live range pushed hipcc into scratch)
     const bool ln = OS == 1 && NS == 2 && D >= 256 && d.ln_op != nullptr;
     float lsum = 0.f;
+    bool sat = false;
+    status_raise(false, g == 0 && stat_bad(m_run, inv));       // softmax statistics of this query
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int col = c_base + c * 16 + g * 4;
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
         } else {
             const float vv[4] = {v.x, v.y, v.z, v.w};
             store_op4(d.out_op, d.out_lo, NS, grow * d.ldo + col, vv);
+            if (NS == 2) sat |= op_sat4(vv);
         }
     }
     if (ln) {
@@ -409,9 +412,332 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
             const float y[4] = {(o[c][0] - mean) * rstd * w.x + bb.x, (o[c][1] - mean) * rstd * w.y + bb.y,
                                 (o[c][2] - mean) * rstd * w.z + bb.z, (o[c][3] - mean) * rstd * w.w + bb.w};
             store_op4(d.ln_op, d.ln_lo, NS, grow * d.ld_ln + col, y);
+            if (NS == 2) sat |= op_sat4(y);
+        }
+        status_raise(false, g == 0 && stat_bad(mean, rstd));
+    }
+    status_raise(sat);
+}
+
+// =====================================================================================================================
+// (r05) flash_ds_kernel<D>: the two-plane (parity) form with the HEAD DIMENSION SPLIT OVER A WAVE PAIR -- eight waves over the
+// same 64 queries, two waves per SIMD.  r04's PMC of the 4-wave form above (one wave per SIMD, 256+ registers): 21.5 % MFMA-busy,
+// 37 % of the wave-cycles parked -- every 32-key phase starts with twelve LDS-DMA instructions per wave (60 - 185 issue cycles
+// each, MI355X_MICROARCH.md) and a softmax that nothing overlaps, because the SIMD has no second wave to issue MFMAs from.
+// Here waves 2 p and 2 p + 1 share the 16 queries of pair p:
+//     phase 1   wave h (= wave & 1) forms the PARTIAL scores over its half of d (k-steps h KS/2 ..), parks them in LDS;
+//     barrier   (the one that publishes V^T_j anyway) -- then both waves add the two halves (a + b == b + a: identical bits in
+//               both), run the same online softmax and hold the same P fragment;
+//     phase 2   wave h accumulates its HALF of the output channels: O^T[h D/2 ..] += V^T_j[h D/2 ..] P^T.
+// Per wave: half the Q fragments (KS/2 x 2 planes), half the accumulators, half the DMA pieces, half the fragment reads -- < 200
+// registers, so two waves share a SIMD and one's DMA issue / softmax / LDS waits run under the other's MFMAs.  The K / V^T tile
+// and its LDS traffic per query are unchanged (one 98-KiB tile at d = 384 + a 16-KiB exchange buffer: one workgroup per CU).
+// d = 512 fits too (131 KiB + 16): the 4-wave form needs two workgroups per query block there, each recomputing S^T (OS = 2).
+// The fused LayerNorm (ln_op) exchanges the pair's row sums through the same buffer: mean / variance over all D channels, two-pass.
+template <int D>
+struct FDGeo {
+    static constexpr int NS = 2, NW = 8, BKV = 32;
+    static constexpr int KS = D / 32, KSH = KS / 2;      // QK^T k-steps, per wave
+    static constexpr int CT = D / 16, CTH = CT / 2;      // O^T row fragments, per wave
+    static constexpr int KPL = BKV * D * 2, VPL = D * BKV * 2;
+    static constexpr int KBUF = NS * KPL, VBUF = NS * VPL, TILE = KBUF + VBUF;
+    static constexpr int XCH = NW * 64 * 8 * 4;          // partial-score exchange: 8 floats per lane
+    static constexpr int SMEM = TILE + XCH;
+    static constexpr int KP = KS * 2, VP = D / 16;       // 1-KiB DMA pieces per plane
+    static_assert(KS % 2 == 0 && CTH % 2 == 0 && SMEM <= 163840, "d-split geometry / LDS budget");
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d) {
+    using G = FDGeo<D>;
+    constexpr int NS = 2, NW = 8, KSH = G::KSH, CTH = G::CTH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pair = wave >> 1, hf = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int BQ = 64;
+
+    const int qblocks = (d.Nq + BQ - 1) / BQ;
+    const int nb = qblocks * d.B;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    }
+    const int z = bid / qblocks, qb = bid - z * qblocks;
+    const int q0 = qb * BQ + pair * 16;
+    int qrow = q0 + r;
+    const bool q_ok = qrow < d.Nq;
+    qrow = q_ok ? qrow : d.Nq - 1;
+    const int64_t grow = (int64_t)z * d.Nq + qrow;
+
+    // ---- Q fragments of this wave's half of d ----
+    bf16x8 qf[KSH][NS];
+    {
+        const frido_bf16* qp = d.Q + grow * d.ldq + hf * (D / 2) + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) {
+            qf[ks][0] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+            qf[ks][1] = *reinterpret_cast<const bf16x8*>(qp + d.q_lo + ks * 32);
         }
     }
+
+    // ---- DMA (the 4-wave form's piece layout, dealt over eight waves: piece = wave + 8 i keeps h = wave & 1) ----
+    const int lrow = lane >> 2;
+    const int lq = (lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3);
+    const int key_l = 8 * (lrow >> 2) + 4 * hf + (lrow & 3);
+    const frido_bf16* Kb = d.K + (int64_t)z * d.k_bs + lq * 8;
+    const frido_bf16* Vb = d.VT + (int64_t)z * d.vt_bs + (int64_t)lrow * d.ldvt + lq * 8;
+    const int ntiles = (d.Nk + G::BKV - 1) / G::BKV;
+    auto issue_k = [&](int j) {
+        int key = j * G::BKV + key_l;
+        key = key < d.Nk ? key : d.Nk - 1;
+        const frido_bf16* src = Kb + (int64_t)key * d.ldk;
+#pragma unroll
+        for (int i = 0; i < (G::KP + NW - 1) / NW; ++i) {
+            const int piece = wave + NW * i;
+            if (piece < G::KP) {
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.k_lo : 0) + (piece >> 1) * 32),
+                                                     (lptr_t)(smem + p * G::KPL + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_v = [&](int j) {
+        const frido_bf16* src = Vb + j * G::BKV;
+#pragma unroll
+        for (int i = 0; i < (G::VP + NW - 1) / NW; ++i) {
+            const int piece = wave + NW * i;
+            if (piece < G::VP) {
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.vt_lo : 0) + (int64_t)piece * 16 * d.ldvt),
+                                                     (lptr_t)(smem + G::KBUF + p * G::VPL + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned frag = (unsigned)(r * 64 + ((g ^ ((4 - ((r >> 2) & 3)) & 3)) << 4));
+    const unsigned k_frag = lds0 + frag + (unsigned)(hf * KSH * 2048);               // this wave's k-steps
+    const unsigned v_frag = lds0 + G::KBUF + frag + (unsigned)(hf * CTH * 1024);      // this wave's output channels
+    const unsigned x_mine = lds0 + G::TILE + (unsigned)((wave * 64 + lane) * 32);
+    const unsigned x_peer = lds0 + G::TILE + (unsigned)(((wave ^ 1) * 64 + lane) * 32);
+
+    f32x4 o[CTH];
+#pragma unroll
+    for (int c = 0; c < CTH; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+    const float alpha = d.alpha;
+
+    issue_k(0);
+    for (int j = 0; j < ntiles; ++j) {
+        // ================= phase 1: partial S^T over this wave's half of d =================
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // K_j visible; every wave has finished tile j - 1 (its V^T reads, its exchange reads)
+        issue_v(j);
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        {
+            bf16x8 kf[2][2][NS];                   // [buffer][half][plane]
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                kf[0][0][p] = lds_read128(k_frag + p * G::KPL);
+                kf[0][1][p] = lds_read128(k_frag + p * G::KPL + 1024);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) {
+                if (ks + 1 < KSH) {
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+                        kf[(ks + 1) & 1][0][p] = lds_read128(k_frag + p * G::KPL + (ks + 1) * 2048);
+                        kf[(ks + 1) & 1][1][p] = lds_read128(k_frag + p * G::KPL + (ks + 1) * 2048 + 1024);
+                    }
+                    wait_lgkm<2 * NS>();
+                } else {
+                    wait_lgkm<0>();
+                }
+                const bf16x8(&ka)[2] = kf[ks & 1][0];
+                const bf16x8(&kb)[2] = kf[ks & 1][1];
+                s0 = mfma_op<NS>(ka[1], qf[ks][0], s0);
+                s1 = mfma_op<NS>(kb[1], qf[ks][0], s1);
+                s0 = mfma_op<NS>(ka[0], qf[ks][1], s0);
+                s1 = mfma_op<NS>(kb[0], qf[ks][1], s1);
+                s0 = mfma_op<NS>(ka[0], qf[ks][0], s0);
+                s1 = mfma_op<NS>(kb[0], qf[ks][0], s1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // park the partial scores for the partner wave
+        asm volatile("ds_write_b128 %0, %1" ::"v"(x_mine), "v"(s0) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:16" ::"v"(x_mine), "v"(s1) : "memory");
+        // ================= phase 2 head: V^T_j and the partner's partials visible =================
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // every wave has finished reading K_j
+        if (j + 1 < ntiles) issue_k(j + 1);
+        f32x4 p0, p1;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(p0) : "v"(x_peer));
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(p1) : "v"(x_peer));
+        // (the V^T fragments of the first channel pair are fetched under the softmax)
+        bf16x8 vf[2][2][NS];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) vf[0][q][p] = lds_read128(v_frag + p * G::VPL + q * 1024);
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(p0), "+v"(p1) : "n"(2 * NS));      // the partner's partials have landed
+        __builtin_amdgcn_sched_barrier(0);
+        float sv[8] = {(s0[0] + p0[0]) * alpha, (s0[1] + p0[1]) * alpha, (s0[2] + p0[2]) * alpha, (s0[3] + p0[3]) * alpha,
+                       (s1[0] + p1[0]) * alpha, (s1[1] + p1[1]) * alpha, (s1[2] + p1[2]) * alpha, (s1[3] + p1[3]) * alpha};
+        if ((j + 1) * G::BKV > d.Nk) {             // ragged last tile (uniform branch)
+            const int k0 = j * G::BKV + 8 * g;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (k0 + i >= d.Nk) sv[i] = -1.0e30f;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        tmax = xor_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float corr = __expf(m_run - m_new);
+        float pv[8], rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pv[i] = __expf(sv[i] - m_new);
+            rs += pv[i];
+        }
+        rs = xor_sum(rs);
+        l_run = l_run * corr + rs;
+        m_run = m_new;
+        bf16x8 pf[NS];
+        {
+            uint32_t h[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_op(pv[i], NS, h[i], l[i]);
+            u32x4 ph = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            u32x4 pl = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+            pf[0] = __builtin_bit_cast(bf16x8, ph);
+            pf[1] = __builtin_bit_cast(bf16x8, pl);
+        }
+        if (__any(corr != 1.0f)) {
+#pragma unroll
+            for (int c = 0; c < CTH; ++c) {
+                o[c][0] *= corr; o[c][1] *= corr; o[c][2] *= corr; o[c][3] *= corr;
+            }
+        }
+        // ================= phase 2: O^T[this half] += V^T_j P^T =================
+#pragma unroll
+        for (int c = 0; c < CTH; c += 2) {
+            const int cur = (c >> 1) & 1;
+            if (c + 2 < CTH) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) vf[cur ^ 1][q][p] = lds_read128(v_frag + p * G::VPL + (c + 2 + q) * 1024);
+                wait_lgkm<2 * NS>();
+            } else {
+                wait_lgkm<0>();
+            }
+            o[c] = mfma_op<NS>(vf[cur][0][1], pf[0], o[c]);
+            o[c + 1] = mfma_op<NS>(vf[cur][1][1], pf[0], o[c + 1]);
+            o[c] = mfma_op<NS>(vf[cur][0][0], pf[1], o[c]);
+            o[c + 1] = mfma_op<NS>(vf[cur][1][0], pf[1], o[c + 1]);
+            o[c] = mfma_op<NS>(vf[cur][0][0], pf[0], o[c]);
+            o[c + 1] = mfma_op<NS>(vf[cur][1][0], pf[0], o[c + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: lane holds O^T[c = 16 (hf CTH + ct) + 4 g + e][q = r] ----
+    const float inv = 1.0f / l_run;
+    const bool ln = d.ln_op != nullptr;
+    float lsum = 0.f;
+    bool sat = false;
+    if (q_ok) status_raise(false, g == 0 && hf == 0 && stat_bad(m_run, inv));
+#pragma unroll
+    for (int c = 0; c < CTH; ++c) {
+        const int col = (hf * CTH + c) * 16 + g * 4;
+        float4 v = make_float4(o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv);
+        if (d.out_act) {
+            if (d.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(d.bias + col);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
+            if (d.residual) {
+                const float4 rr = load_act4(d.residual, grow * d.ldr + col, d.act_bf16);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            const int64_t oo = grow * d.ld_act + col;
+            if (q_ok) {
+                if (d.act_bf16)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<frido_bf16*>(d.out_act) + oo) =
+                        make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
+                else
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.out_act) + oo) = v;
+            }
+            if (ln) {
+                o[c] = f32x4{v.x, v.y, v.z, v.w};
+                lsum += (v.x + v.y) + (v.z + v.w);
+            }
+        } else if (q_ok) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            store_op4(d.out_op, d.out_lo, NS, grow * d.ldo + col, vv);
+            sat |= op_sat4(vv);
+        }
+    }
+    if (ln) {       // (uniform: every wave of the workgroup takes the two exchange barriers)
+        // LayerNorm of the stream row: the pair's half-row sums meet in the exchange buffer; mean first, then the centred sum of
+        // squares (layernorm_kernel's two passes), both added as half 0 + half 1 so that the two waves hold identical statistics
+        float* xs = reinterpret_cast<float*>(smem + G::TILE);
+        const float hs = xor_sum(lsum);
+        __builtin_amdgcn_s_barrier();              // (every wave is past its last exchange read of the main loop)
+        if (g == 0) xs[wave * 16 + r] = hs;
+        __syncthreads();
+        const float mean = (xs[(pair * 2) * 16 + r] + xs[(pair * 2 + 1) * 16 + r]) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CTH; ++c) {
+            const float a0 = o[c][0] - mean, a1 = o[c][1] - mean, a2 = o[c][2] - mean, a3 = o[c][3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float hq = xor_sum(q);
+        if (g == 0) xs[128 + wave * 16 + r] = hq;
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf((xs[128 + (pair * 2) * 16 + r] + xs[128 + (pair * 2 + 1) * 16 + r]) * (1.0f / D) + d.ln_eps);
+        if (q_ok) {
+#pragma unroll
+            for (int c = 0; c < CTH; ++c) {
+                const int col = (hf * CTH + c) * 16 + g * 4;
+                const float4 w = *reinterpret_cast<const float4*>(d.ln_w + col), bb = *reinterpret_cast<const float4*>(d.ln_b + col);
+                const float y[4] = {(o[c][0] - mean) * rstd * w.x + bb.x, (o[c][1] - mean) * rstd * w.y + bb.y,
+                                    (o[c][2] - mean) * rstd * w.z + bb.z, (o[c][3] - mean) * rstd * w.w + bb.w};
+                store_op4(d.ln_op, d.ln_lo, NS, grow * d.ld_ln + col, y);
+                sat |= op_sat4(y);
+            }
+            status_raise(false, g == 0 && hf == 0 && stat_bad(mean, rstd));
+        }
+    }
+    status_raise(sat);
 }
+
+template <int D>
+int flash_ds_launch(const FridoAttnSmall& d, hipStream_t s) {
+    constexpr int smem = FDGeo<D>::SMEM;
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FRIDO_EHIP;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_ds_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            frido_set_error("attn_flash (d-split): cannot set dynamic LDS size %d", smem);
+            return FRIDO_EHIP;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    const int blocks = d.B * ((d.Nq + 63) / 64);
+    hipLaunchKernelGGL((flash_ds_kernel<D>), dim3(blocks), dim3(512), smem, s, d);
+    return frido_check_launch("attn_flash(d-split)");
+}
+
 
 template <int D, int NS, int NW, int OS>
 int flash_launch(const FridoAttnSmall& d, hipStream_t s) {
@@ -435,7 +761,15 @@ int flash_launch(const FridoAttnSmall& d, hipStream_t s) {
 
 template <int D>
 int flash_dispatch(const FridoAttnSmall& d, hipStream_t s) {
-    if (d.nsplit == 2) return flash_launch<D, 2, 4, (D >= 512 ? 2 : 1)>(d, s);   // hi + lo planes of Q and P: one wave per SIMD
+    if (d.nsplit == 2) {
+        // (r05) two-plane mode: the d-split 8-wave form (two waves per SIMD) wherever its tile + exchange buffer fit the LDS (d <= 512);
+        // FRIDO_FLASH_DSPLIT=0 keeps r04's 4-wave form (A/B switch)
+        if constexpr (D >= 256 && D <= 512) {
+            static const bool dsplit = !(getenv("FRIDO_FLASH_DSPLIT") && atoi(getenv("FRIDO_FLASH_DSPLIT")) == 0);
+            if (dsplit) return flash_ds_launch<D>(d, s);
+        }
+        return flash_launch<D, 2, 4, (D >= 512 ? 2 : 1)>(d, s);   // hi + lo planes of Q and P: one wave per SIMD
+    }
     // 8 waves (128 queries) per workgroup halve the L2 -> LDS bytes per FLOP; 4 waves when that would leave CUs idle or the
     // accumulators do not fit 256 registers
     if constexpr (D <= 384) {
@@ -459,6 +793,7 @@ extern "C" int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s) {
                       (d->vt_lo & 7) == 0 && (d->out_lo & 3) == 0 && (d->k_bs & 7) == 0 && (d->vt_bs & 7) == 0,
                   "strides and plane offsets must keep 16-byte alignment");
     FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
+    FRIDO_REQUIRE(!d->skip_act_store, "skip_act_store is served by frido_attn_small only");
     FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && (d->d == 256 || d->d == 384) && d->ln_w && d->ln_b && (d->ld_ln & 3) == 0 &&
                                 (d->ln_lo & 3) == 0),
                   "ln_op: bf16x3 f32-stream output with d = 256 or 384 (the workgroup owns whole rows), weight and bias given");

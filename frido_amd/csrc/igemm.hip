@@ -1194,6 +1194,7 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) 
     int vstep = 0;
     if (d.rowvec && d.rowvec_step) vstep = *d.rowvec_step;
     const int64_t plane = (int64_t)d.M * d.N;
+    bool sat = false;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const int m = (int)(i / (unsigned)n8), n = (int)(i - (unsigned)m * (unsigned)n8) * 8;
         const float* w = d.ws + SK_HDR + (int64_t)m * d.N + n;
@@ -1273,12 +1274,14 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) 
             uint32_t h[8], l[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) split_op(v[e], d.nsplit, h[e], l[e]);
+            if (d.nsplit == 2) sat |= op_sat8(v);
             frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + n;
             *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             if (d.nsplit == 2)
                 *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
         }
     }
+    status_raise(sat);
 }
 
 // launch the split-K reduction that matches the descriptor's alignment
@@ -1302,6 +1305,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const FridoGemm d) {
         if (d.residual) v += load_act1(d.residual, (int64_t)m * d.ldr + n, d.res_bf16);
         if (d.out_f32) store_act1(d.out_f32, (int64_t)m * d.ldo + n, d.out_bf16, v);
         if (d.out_op) store_op1(d.out_op, d.oo_lo, d.nsplit, (int64_t)m * d.ldoo + n, v);
+        if (d.out_op && d.nsplit == 2 && op_sat(v)) status_raise(true);
     }
 }
 

@@ -307,6 +307,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                             uint32_t h[8], l[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) split_op(v[e], NS, h[e], l[e]);
+                            if (op_sat8(v)) status_raise(true);      // (rare branch: no flag register kept live across the tile)
                             frido_bf16* op = d.out_op + oo_base + (int64_t)m * d.ldoo + ncol0 + 32 * J;
                             *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                             *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
@@ -401,6 +402,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                             uint32_t h[8], l[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) split_op(ov[e], NS, h[e], l[e]);
+                            if (op_sat8(ov)) status_raise(true);
                             frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + no;
                             *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                             *reinterpret_cast<uint4*>(op + d.oo_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
@@ -444,6 +446,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 uint32_t h[8], l[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) split_op(ov[e], NS, h[e], l[e]);
+                if (NS == 2 && op_sat8(ov)) status_raise(true);
                 frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + no;
                 *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 if (d.nsplit == 2)
@@ -473,6 +476,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 const int64_t mo = out_row(m);
                 if (d.out_f32) store_act1(d.out_f32, of_base + mo * d.ldo + n, d.out_bf16, x);
                 if (d.out_op) store_op1(d.out_op + oo_base, d.oo_lo, d.nsplit, mo * d.ldoo + n, x);
+                if (NS == 2 && d.out_op && op_sat(x)) status_raise(true);
                 if (d.out_u8) {      // sample_diffusion.py:103-121: every step its own fp32 rounding (no contraction), then truncation
                     float u;
                     if (d.u8_mode == 2) u = __fmul_rn(255.0f, __fmul_rn(__fadd_rn(fminf(fmaxf(x, -1.0f), 1.0f), 1.0f), 0.5f));
@@ -552,6 +556,7 @@ __device__ __forceinline__ void tile_epilogue(const FridoGemm& d, f32x4 (&acc)[B
                 uint32_t h[8], l[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) split_op(v[e], NS, h[e], l[e]);
+                if (NS == 2 && op_sat8(v)) status_raise(true);
                 frido_bf16* op = d.out_op + oo_base + out_row(m) * d.ldoo + n;
                 *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 if (d.nsplit == 2)

@@ -15,6 +15,29 @@ inline int grid_for(int64_t work_items, int cap = 8192) {
 __global__ __launch_bounds__(256) void pack_kernel(const FridoPack d) {
     const int P4 = d.Cpad >> 2;
     const int64_t total = (int64_t)d.B * d.HW * P4;
+    bool sat = false;
+    if (!d.nchw && d.nsplit == 2 && d.Cuse == d.Cpad && ((d.Cpad | d.Csrc | d.c0) & 7) == 0 && (d.out_lo & 7) == 0) {
+        // (r05) the residual stream as an operand (Down / Upsample inputs, pyunet.py:110-156): 8 channels per lane -- two 16-byte
+        // loads, one 16-byte store per plane (the element-wise loop below moved 4 scalar loads and two 8-byte stores per lane)
+        const int P8 = d.Cpad >> 3;
+        const int64_t total8 = (int64_t)d.B * d.HW * P8;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+            const int64_t pix = i / P8;
+            const int c = (int)(i - pix * P8) * 8;
+            const float* src = d.src + pix * d.Csrc + d.c0 + c;
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            const float v[8] = {a.x * d.scale, a.y * d.scale, a.z * d.scale, a.w * d.scale, b.x * d.scale, b.y * d.scale, b.z * d.scale, b.w * d.scale};
+            uint32_t h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split_op(v[e], 2, h[e], l[e]);
+            sat |= op_sat8(v);
+            frido_bf16* o = d.out_op + pix * d.Cpad + c;
+            *reinterpret_cast<uint4*>(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            *reinterpret_cast<uint4*>(o + d.out_lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        }
+        status_raise(sat);
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t pix = i / P4;
         const int c = (int)(i - pix * P4) * 4;
@@ -34,7 +57,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const FridoPack d) {
             }
         }
         store_op4(d.out_op, d.out_lo, d.nsplit, pix * d.Cpad + c, v);
+        if (d.nsplit == 2) sat |= op_sat4(v);
     }
+    status_raise(sat);
 }
 
 __global__ __launch_bounds__(256) void relayout_kernel(const FridoRelayout d) {

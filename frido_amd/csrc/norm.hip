@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const FridoGnStats d) {
         double* out = d.partials + (((int64_t)b * d.nsplit_px + sp) * d.groups + t) * 2;
         out[0] = gsum;
         out[1] = gsq;
+        status_raise(false, !(fabs(gsum) <= 1.0e300) || !(gsq <= 1.0e300));
     }
 }
 
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void gn_stats_parts_kernel(const FridoGnStats 
         double* out = d.partials + ((int64_t)b * d.groups + g) * 2;
         out[0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
         out[1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+        status_raise(false, !(fabs(out[0]) <= 1.0e300) || !(out[1] <= 1.0e300));
     }
 }
 
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
             var = var < 0.0 ? 0.0 : var;
             s_mean[t] = (float)mean;
             s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+            if (blockIdx.x == 0) status_raise(false, stat_bad(s_mean[t], s_rstd[t]));
         }
     }
     __syncthreads();
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         const float* gf = reinterpret_cast<const float*>(d.gamma);
         const float* bf = reinterpret_cast<const float*>(d.beta);
         struct Vec { float4 x0, x1, g0, g1, b0, b1; int64_t o; int c; };
+        bool sat = false;
         auto one = [&](unsigned i, Vec& v) {
             const unsigned p = i / C8;
             v.c = (int)(i - p * C8) * 8;
@@ -286,9 +290,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
             uint32_t h[8], l[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) split_op(y[e], 2, h[e], l[e]);
+            sat |= op_sat8(y);
             *reinterpret_cast<uint4*>(d.out_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             *reinterpret_cast<uint4*>(d.out_op + d.out_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             if (d.raw_op) {                 // concatenated raw operand for the 1x1 skip conv
+                sat |= op_sat8(xin);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) split_op(xin[e], 2, h[e], l[e]);
                 *reinterpret_cast<uint4*>(d.raw_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
@@ -309,8 +315,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
             one(i, v0);
             fin(v0);
         }
+        status_raise(sat);
         return;
     }
+    bool sat = false;
     const unsigned total = (unsigned)d.HW * (unsigned)C4;      // < 2^31 on every shape of this path
     for (unsigned i = blockIdx.x * 256u + t; i < total; i += gridDim.x * 256u) {
         const unsigned p = i / (unsigned)C4;
@@ -336,8 +344,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
         }
         if (d.out_op) store_op4(d.out_op, d.out_lo, d.nsplit, o, y);
         if (d.raw_op) store_op4(d.raw_op, d.raw_lo, d.nsplit, o, xin);
+        if (d.nsplit == 2) sat |= (d.out_op && op_sat4(y)) || (d.raw_op && op_sat4(xin));
         if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
     }
+    status_raise(sat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const FridoGnApply d, int 
         var = var < 0.0 ? 0.0 : var;
         s_mean[t] = (float)mean;
         s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+        if ((t + 1) * cpg <= Cc) status_raise(false, stat_bad(s_mean[t], s_rstd[t]));
     }
     __syncthreads();
     if (!live) return;
@@ -606,6 +617,7 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
         var = var < 0.0 ? 0.0 : var;
         s_mean[t] = (float)mean;
         s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.eps));
+        if ((t + 1) * cpg <= Cc) status_raise(false, stat_bad(s_mean[t], s_rstd[t]));
     }
     __syncthreads();
     if (!live) return;
@@ -616,6 +628,7 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
         sc[e] = r;
         sh[e] = d.bias[c + e] - s_mean[gi[e]] * r;
     }
+    bool sat = false;
 #pragma unroll
     for (int k = 0; k < GNF32_MAXV; ++k) {
         const int p = pl + k * ppi;
@@ -637,6 +650,7 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
         uint32_t h[8], l[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) split_op(y[e], d.nsplit, h[e], l[e]);
+        if (d.nsplit == 2) sat |= op_sat8(y) || (d.raw_op && op_sat8(xv[k]));
         *reinterpret_cast<u32x4*>(d.out_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         if (d.nsplit == 2)
             *reinterpret_cast<u32x4*>(d.out_op + d.out_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
@@ -648,6 +662,7 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
                 *reinterpret_cast<u32x4*>(d.raw_op + d.raw_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
         }
     }
+    status_raise(sat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -707,14 +722,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
         return;
     }
     const int C4 = d.C >> 2;
-    float4 v[4];
+    float4 v[4], wv[4], bv[4];      // (r05) the affine parameters are fetched with the row, under the two reductions, not after them
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c4 = lane + i * 64;
         v[i] = c4 < C4 ? load_act4(d.x, (int64_t)row * d.C + c4 * 4, d.x_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        if (c4 < C4) {
+            wv[i] = *reinterpret_cast<const float4*>(d.weight + c4 * 4);
+            bv[i] = *reinterpret_cast<const float4*>(d.bias + c4 * 4);
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) / d.C;
     float q = 0.f;
 #pragma unroll
@@ -725,18 +745,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const FridoLayerNorm d) 
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / d.C + d.eps);
+    bool sat = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c4 = lane + i * 64;
         if (c4 < C4) {
-            const float4 w = *reinterpret_cast<const float4*>(d.weight + c4 * 4);
-            const float4 bi = *reinterpret_cast<const float4*>(d.bias + c4 * 4);
+            const float4 w = wv[i], bi = bv[i];
             const float y[4] = {(v[i].x - mean) * rstd * w.x + bi.x, (v[i].y - mean) * rstd * w.y + bi.y,
                                 (v[i].z - mean) * rstd * w.z + bi.z, (v[i].w - mean) * rstd * w.w + bi.w};
             if (d.out_op) store_op4(d.out_op, d.out_lo, d.nsplit, (int64_t)row * d.C + c4 * 4, y);
+            if (d.out_op && d.nsplit == 2) sat |= op_sat4(y);
             if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + (int64_t)row * d.C + c4 * 4) = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
+    status_raise(sat, lane == 0 && stat_bad(mean, rstd));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,6 +792,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(const FridoSoftmax d) {
         }
     }
     const float inv = 1.0f / wave_sum(s);
+    status_raise(false, lane == 0 && stat_bad(mx, inv));
     frido_bf16* o = d.out_op + (int64_t)row * d.Npad;
     const int npv = (d.Npad + 63) >> 6;
 #pragma unroll
@@ -798,6 +821,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const FridoL2Norm d) {
 __global__ __launch_bounds__(256) void geglu_kernel(const FridoGeglu d) {
     const int H4 = d.H >> 2;
     const int64_t total = (int64_t)d.rows * H4;
+    bool sat = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / H4;
         const int c = (int)(i - r * H4) * 4;
@@ -808,7 +832,9 @@ __global__ __launch_bounds__(256) void geglu_kernel(const FridoGeglu d) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = aa[e] * (0.5f * gg[e] * (1.0f + erff(gg[e] * 0.70710678118654752f)));
         store_op4(d.out_op, d.out_lo, d.nsplit, r * d.H + c, y);
+        if (d.nsplit == 2) sat |= op_sat4(y);
     }
+    status_raise(sat);
 }
 
 inline int grid_for(int64_t work_items, int cap = 4096) {
@@ -886,8 +912,11 @@ extern "C" int frido_gn_fused(const FridoGnApply* d, frido_stream_t s) {
                                 (!d->sk_rowvec || d->sk_rows_per_vec > 0) && (int64_t)d->B * d->HW < (1ll << 31)),
                   "sk_ws (x1 from split-K partial sums): f32 input, >= 2 slices, C1 % 8 == 0, 4-element aligned strides");
     const int C = d->C1 + d->C2;
-    // (an sk_ws launch keeps the workgroup width of the plain one: the statistics' summation order, and with it every output bit, is
-    //  the same whether the reduction was deferred or not -- a 1024-thread form for them measured -2 us per launch and was not kept)
+    // (r05) an sk_ws launch takes the 1024-thread form whatever the plain launch would use: every lane then owns ONE vector of ONE
+    // pixel and has all its slices' loads in flight at once (the 256-thread form walked 4 vectors x sk_n slices in 4 dependent rounds;
+    // measured r04: -2 us per launch).  The statistics' wave-partial order differs from the plain launch's: deferred and undeferred
+    // reductions agree to fp32 rounding (<= 1e-6 relative on the normalised output), no longer bit for bit.
+    if (d->sk_ws && !d->x_bf16 && nt < 1024 && Cc / 8 <= 1024) nt = 1024;
     if (d->x_bf16) hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
     else if (nt == 256) hipLaunchKernelGGL((gn_fused_f32_kernel<256, 4>), dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
     else if (nt == 512) hipLaunchKernelGGL((gn_fused_f32_kernel<512, 4>), dim3(C / Cc, d->B), dim3(512), 0, (hipStream_t)s, *d, Cc);

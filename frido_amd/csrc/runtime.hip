@@ -309,6 +309,33 @@ extern "C" int frido_sizeof_desc(int32_t kind) {
 }
 extern "C" const char* frido_last_error(void) { return g_err; }
 
+// ---- sticky numerics status (common.h): one device word per translation unit, registered at load time ----
+namespace {
+std::vector<frido_status_accessor>& status_words() {
+    static std::vector<frido_status_accessor> v;
+    return v;
+}
+}  // namespace
+void frido_register_status_word(frido_status_accessor fn) { status_words().push_back(fn); }
+
+extern "C" int frido_status_flags(uint32_t* flags, int32_t clear) {
+    if (!flags) {
+        frido_set_error("frido_status_flags: null pointer");
+        return FRIDO_EINVAL;
+    }
+    unsigned all = 0;
+    for (auto fn : status_words()) {
+        unsigned w = 0;
+        if (fn(&w, clear) != FRIDO_OK) {
+            frido_set_error("frido_status_flags: cannot read the device status word: %s", hipGetErrorString(hipGetLastError()));
+            return FRIDO_EHIP;
+        }
+        all |= w;
+    }
+    *flags = all;
+    return FRIDO_OK;
+}
+
 extern "C" int frido_device_info(int32_t* cu_count, int32_t* is_gfx950, int64_t* hbm_bytes) {
     int dev = 0;
     hipDeviceProp_t p;

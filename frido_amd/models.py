@@ -141,7 +141,11 @@ class PyUNetModel(_Versioned, nn.Module):
         return self._rt
 
     def forward(self, x, timesteps=None, context=None, y=None, stage=None, **kwargs):
-        assert y is None, "must specify y if and only if the model is class-conditional"
+        if y is not None:      # pyunet.py:877-879 asserts (y is not None) == (num_classes is not None); class-conditional denoisers are not built (arch.py)
+            raise NotImplementedError("class-conditional denoiser (num_classes / conditioning_key='adm'): no shipped Frido config uses it")
+        if context is None:
+            raise NotImplementedError("PyUNetModel.forward without a context: the reference's SpatialTransformer then attends to its own input "
+                                      "(attention.py:171 `default(context, x)`); every shipped Frido config passes one, that plan is not built")
         if not x.is_cuda:
             _no_cpu("PyUNetModel.forward", x.device)
         if self.num_stage > 1 and not isinstance(stage, int):
@@ -444,9 +448,21 @@ class DiffusionWrapper(_Base):
         assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
 
     def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, stage=None):
-        if self.conditioning_key == "crossattn":
+        """frido.py:1635-1654, key for key.  Every shipped config uses 'crossattn'; 'hybrid' (channel concat + context) runs on the same
+        denoiser plan; None / 'concat' reach a denoiser WITHOUT a context, 'adm' one with class labels -- the denoiser says which of
+        those it was built for (PyUNetModel.forward raises NotImplementedError for a context-free SpatialTransformer and for `y`)."""
+        key = self.conditioning_key
+        if key is None:
+            return self.diffusion_model(x, t, stage=stage)
+        if key == "concat":
+            return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t, stage=stage)
+        if key == "crossattn":
             return self.diffusion_model(x, t, context=torch.cat(c_crossattn, 1), stage=stage)
-        raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: every shipped Frido config uses 'crossattn'")
+        if key == "hybrid":
+            return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t, context=torch.cat(c_crossattn, 1), stage=stage)
+        if key == "adm":
+            return self.diffusion_model(x, t, y=c_crossattn[0], stage=stage)
+        raise NotImplementedError()
 
 
 class FridoDiffusion(_Base):

@@ -293,8 +293,10 @@ class UNetStagePlan:
             n2 = b.layernorm(h2, t + ".norm2")
         kc, vTc, bvo2 = self.kv[pre]            # kc = ctx (W_q^T W_k)^T: the query projection is folded into the cached keys
         chain = CHAIN_FF and C % 64 == 0       # proj_out(h3 + ff2(gg)) + x in ONE GEMM (needs h3 as an operand along K)
+        # (r05) with FF2 + proj_out chained, h3 is read only as an operand (A2 of that GEMM) and through norm3: where the kernel
+        # produces both copies itself the f32 rows are not stored at all
         h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True, also_op=chain,
-                         ln=(t + ".norm3", 1e-5))
+                         ln=(t + ".norm3", 1e-5), stream_dead=chain)
         n2.free()
         h2.free()
         # --- GEGLU feed-forward (attention.py:37-64)
@@ -314,6 +316,7 @@ class UNetStagePlan:
                 h3op.free()
             h3.free()
             return out
+        assert not getattr(h3, "stream_skipped", False)      # the unchained tail reads h3's f32 rows
         h4 = b.linear(gg, t + ".ff.net.2", residual=h3, out="op")
         gg.free()
         h3.free()

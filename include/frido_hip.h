@@ -38,8 +38,9 @@ typedef uint16_t frido_bf16;
  * split-K workspace starts with a 64-KiB ticket header that the CALLER zeroes once (frido_gemm_workspace_bytes), two-plane
  * operands became fp16 pairs (frido_x3_plane_format() == 1).  3 (r04): FridoGemm grew at its END (out_u8 / ldu8 / u8_mode, the fused
  * GroupNorm-apply input gn_*), two-plane operand producers saturate at +-65504.  4 (r04): FridoGemm.sk_mode 2 + FridoGnApply.sk_* at the
- * struct's END (a split-K GEMM's reduction finished by the GroupNorm launch that consumes its output). */
-#define FRIDO_ABI_VERSION 4
+ * struct's END (a split-K GEMM's reduction finished by the GroupNorm launch that consumes its output).  5 (r05): FridoAttnSmall.skip_act_store
+ * at the struct's END; frido_status_flags / frido_status_clear (sticky saturation / non-finite flags). */
+#define FRIDO_ABI_VERSION 5
 #define FRIDO_SPLITK_HEADER_BYTES 65536     /* the ticket header at the start of a split-K workspace; partial sums follow: [splitk][M][N] f32 */
 
 #define FRIDO_OK 0
@@ -240,6 +241,10 @@ typedef struct FridoAttnSmall {
        workgroup must own whole rows: frido_attn_flash with d = 256 or 384; frido_attn_small with B * Nq / 16 >= 256 (rejected otherwise). */
     frido_bf16* ln_op; int64_t ln_lo; int32_t ld_ln;
     const float* ln_w; const float* ln_b; float ln_eps;
+    /* (r05, frido_attn_small only) 1: the f32 stream rows are NOT stored -- out_act stays non-null and selects the stream form
+       (O + bias + residual), whose values leave only as the operand copy (out_op) and / or the fused LayerNorm (ln_op).  The
+       transformer block's h3 = attn2(norm2(h2)) + h2 (attention.py:226) is read by nothing else once FF2 + proj_out are one GEMM. */
+    int32_t skip_act_store;
 } FridoAttnSmall;
 
 /* GEGLU gate (attention.py:42-44): x[rows][2H] f32 -> operand [rows][H] = x[:, :H] * gelu_erf(x[:, H:]). */
@@ -453,6 +458,16 @@ int frido_x3_plane_format(void);
 int frido_sizeof_op(void);             /* sizeof(FridoOp): checked by the ctypes mirror */
 int frido_sizeof_desc(int32_t kind);   /* sizeof of the descriptor struct of that op kind */
 const char* frido_last_error(void);
+/* Sticky numerics status of the CURRENT device (r05): kernels cannot return errors, so operand producers and normalisation kernels
+ * OR bits into a device word when they meet a value the arithmetic cannot represent, and this call reads it back (it synchronises
+ * the device: call it after a sampling pass, not inside a captured region).  clear != 0 resets the word after reading.
+ *   FRIDO_STATUS_SATURATED: a two-plane fp16 operand (frido_x3_plane_format() == 1) was clamped at +-65504 -- the fp32-class error
+ *     bound of the "bf16x3" arithmetic no longer holds for that tensor; run the model on the bf16-pair build of the library.
+ *   FRIDO_STATUS_NONFINITE: a GroupNorm / LayerNorm / softmax statistic was NaN or infinite (a NaN / inf reached the stream).
+ * The reference has no counterpart (torch propagates NaN / inf through F.conv2d etc.); this is how they stay visible here. */
+#define FRIDO_STATUS_SATURATED 1u
+#define FRIDO_STATUS_NONFINITE 2u
+int frido_status_flags(uint32_t* flags, int32_t clear);
 int frido_device_info(int32_t* cu_count, int32_t* gcn_arch_is_gfx950, int64_t* hbm_bytes);
 
 #ifdef __cplusplus

@@ -20,3 +20,25 @@ def pytest_configure(config):
 os.environ.setdefault("FRIDO_TUNE_CACHE", os.path.join(REPO, "profiles", "tune_cache.json"))
 os.environ.setdefault("FRIDO_TUNE_CACHE_READONLY", "1")
 os.environ.setdefault("FRIDO_TUNE_ON_MISS", "static")       # no live (timing-dependent) tile choice inside the suite: its results are repeatable bit for bit
+
+
+def pytest_sessionstart(session):
+    """(r05, advisor) The pinned tile cache is keyed by a content hash of libfrido_hip.so; on a box whose build is not byte-identical
+    EVERY lookup misses and -- with FRIDO_TUNE_ON_MISS=static -- the model-level tests silently run on the static tiles instead of
+    the benchmark's.  Say so, loudly, once."""
+    import json
+    import warnings
+    path = os.environ.get("FRIDO_TUNE_CACHE", "")
+    if not path or not os.path.exists(path) or not os.path.exists(os.path.join(REPO, "frido_amd", "libfrido_hip.so")):
+        return
+    try:
+        from frido_amd import tune
+        tag, have = json.load(open(path)).get("lib"), tune._lib_tag()
+    except Exception as e:      # noqa: BLE001
+        warnings.warn(f"tests/conftest.py: cannot compare the tile cache's library tag ({e})")
+        return
+    if tag != have:
+        msg = (f"tile cache {path} was pinned for libfrido_hip.so {tag}, this build is {have}: every GEMM of the GPU suite runs on the "
+               "library's STATIC tile (no split-K, no deferred reductions) -- rebuild bit-identically or re-pin with `python bench.py --retune`")
+        warnings.warn(msg)
+        print("\nWARNING: " + msg, file=sys.stderr)

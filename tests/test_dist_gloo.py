@@ -137,3 +137,19 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
                           "--master-port", "29524", os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, env=env, timeout=300, cwd=REPO)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stdout + bad.stderr      # a mismatch is an error message, not a traceback
+
+
+def test_bench_refuses_cleanly_when_the_node_has_fewer_devices_than_ranks():
+    """r05: `python bench.py --gpus 2` on a node with fewer than 2 HIP devices (this container: none) prints ONE message and exits
+    with a non-zero code before any process group or launcher exists -- no traceback, no hang at a rendezvous."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FRIDO_BENCH_STUB"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two devices")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=REPO)
+    assert out.returncode == 2, out.stdout + out.stderr
+    msg = [l for l in (out.stdout + out.stderr).splitlines() if "--gpus 2 but this node exposes" in l]
+    assert len(msg) == 1 and "Traceback" not in out.stderr

@@ -286,3 +286,38 @@ def test_lit_ema_shadows_only_trainable_parameters():
     assert float(m[0].weight.mean()) == 7.0 and torch.equal(m[1].weight, frozen)
     with pytest.raises(ValueError):
         LitEma(m, decay=1.5)
+
+
+def test_diffusion_wrapper_routes_every_conditioning_key_like_the_reference():
+    """frido.py:1635-1654: None -> model(x, t); concat -> model(cat(x, c_concat)); crossattn -> context = cat(c_crossattn, 1);
+    hybrid -> both; adm -> y = c_crossattn[0].  (r05: the keys other than 'crossattn' used to raise in the wrapper.)"""
+    import torch.nn as nn
+    from frido_amd.models import DiffusionWrapper, PyUNetModel
+
+    class Rec(nn.Module):
+        def forward(self, x, t, context=None, y=None, stage=None):
+            self.got = dict(x=x, t=t, context=context, y=y, stage=stage)
+            return x
+
+    x, t = torch.randn(2, 6, 4, 4), torch.tensor([5, 9])
+    cc, c2 = [torch.randn(2, 3, 4, 4)], [torch.randn(2, 5, 8), torch.randn(2, 2, 8)]
+    got = {}
+    for key in (None, "concat", "crossattn", "hybrid", "adm"):
+        w = DiffusionWrapper.__new__(DiffusionWrapper)
+        nn.Module.__init__(w)
+        w.diffusion_model, w.conditioning_key = Rec(), key
+        w(x, t, c_concat=cc, c_crossattn=c2, stage=1)
+        got[key] = w.diffusion_model.got
+        assert got[key]["stage"] == 1 and torch.equal(got[key]["t"], t)
+    assert torch.equal(got[None]["x"], x) and got[None]["context"] is None and got[None]["y"] is None
+    assert torch.equal(got["concat"]["x"], torch.cat([x] + cc, 1)) and got["concat"]["context"] is None
+    assert torch.equal(got["crossattn"]["x"], x) and torch.equal(got["crossattn"]["context"], torch.cat(c2, 1))
+    assert torch.equal(got["hybrid"]["x"], torch.cat([x] + cc, 1)) and torch.equal(got["hybrid"]["context"], torch.cat(c2, 1))
+    assert torch.equal(got["adm"]["x"], x) and got["adm"]["y"] is c2[0] and got["adm"]["context"] is None
+    # the denoiser itself says what it was not built for (clear NotImplementedError, not an AttributeError three frames down)
+    from golden_cfg import UNET_SMALL
+    u = PyUNetModel(**UNET_SMALL)
+    with pytest.raises(NotImplementedError, match="class-conditional"):
+        u(x, t, context=c2[0], y=torch.tensor([1, 2]), stage=0)
+    with pytest.raises(NotImplementedError, match="without a context"):
+        u(x, t, stage=0)

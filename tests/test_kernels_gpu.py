@@ -724,6 +724,38 @@ def test_vq_lookup(n_codes, e):
     assert float(zq.cpu()[:, :e].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n_codes,e", [(256, 3), (4096, 3), (8192, 4)])
+def test_vq_lookup_exact_indices_on_constructed_ties(n_codes, e):
+    """r05 (r04 verdict, weak 3): the index test without a near-tie allowance.  Latents and codebook live on a 1/32 grid and the scale
+    is a power of two, so every distance term is exactly representable in fp32 whatever the summation order: the argmin is a
+    mathematical fact, ties included.  A third of the codebook is DUPLICATED at higher indices and a quarter of the pixels sit
+    exactly ON a duplicated code: torch.argmin's lowest-index rule (quantize.py:276-294) must hold for every pixel."""
+    from oracle.vqgan import quantize
+    B, H, W = 2, 16, 16
+    Cx = 2 * e
+    cb = torch.round(_t("vqe:cb", n_codes, e) * 32) / 32
+    dup = n_codes // 3
+    cb[n_codes - dup:] = cb[:dup]                    # codes j and n_codes - dup + j coincide: j must win
+    z = torch.round(_t("vqe:z", B, Cx, H, W) * 1.3 * 32) / 32
+    inv = 0.5
+    flat = z[:, e:].permute(0, 2, 3, 1).reshape(-1, e)
+    on = torch.arange(0, flat.shape[0], 4)
+    flat[on] = cb[(on * 7) % dup] / inv              # exactly on a duplicated code (grid / 0.5 stays on the grid)
+    z[:, e:] = flat.view(B, H, W, e).permute(0, 3, 1, 2)
+    zq_ref, idx_ref = quantize(cb, z[:, e:] * inv)
+    b = _builder(2)
+    x_nhwc = z.permute(0, 2, 3, 1).contiguous().cuda()
+    cbd = cb.cuda()
+    zq = torch.zeros(B * H * W, Cx, device="cuda")
+    idx = torch.zeros(B * H * W, dtype=torch.int64, device="cuda")
+    b.prog.emit("FRIDO_OP_VQ", x=x_nhwc.data_ptr(), npix=B * H * W, Cx=Cx, c0=e, e=e, inv_scale=inv,
+                codebook=cbd.data_ptr(), n_codes=n_codes, zq=zq.data_ptr(), Cq=Cx, q0=e, idx=idx.data_ptr())
+    _run(b)
+    assert torch.equal(idx.cpu(), idx_ref.view(-1))
+    assert int((idx.cpu()[on] < dup).sum()) == len(on)            # every on-code pixel took the LOWER of its two equal codes
+    assert torch.equal(zq.cpu()[:, e:].view(B, H, W, e).permute(0, 3, 1, 2), zq_ref)
+
+
 def test_sampler_step_and_handoff_match_oracle():
     from oracle import samplers as S
     B, H, W = 2, 8, 8
@@ -1042,8 +1074,14 @@ def test_splitk_reduction_deferred_into_groupnorm(W, C1, C2, Cout_prev, splitk, 
     if dead:
         assert torch.isnan(x_def).all()             # nobody reads the tensor: it is not materialised
     else:
-        assert torch.equal(x_def, x_ref)
-    assert torch.equal(a_def, a_ref) and torch.equal(raw_def, raw_ref)
+        assert torch.equal(x_def, x_ref)            # the reduction + epilogue arithmetic is splitk_reduce8's, expression for expression
+    assert torch.equal(raw_def, raw_ref)
+    # r05: a deferred launch always takes the 1024-thread form (one vector per lane, all slices' loads in flight), the plain launch the
+    # narrowest form that fits -- the wave-partial order of the statistics differs, so the normalised operand agrees to fp32 rounding
+    # of the statistics (bit for bit where both forms coincide: the 16 x 16 planes)
+    assert _relerr(a_def, a_ref) < 2e-6
+    if HW >= 256:
+        assert torch.equal(a_def, a_ref)
     ref = F.conv2d(xin, wc, bc, padding=1).permute(0, 2, 3, 1).reshape(M, C1) + tvec[2]
     if resid:
         ref = ref + res
@@ -1083,3 +1121,103 @@ def test_gn_conv_rejects_what_it_cannot_run():
     assert b"fused GroupNorm" in _lib.lib().frido_last_error()
     st.tile = 7
     assert _lib.lib().frido_gemm(C_.addressof(st), None) == -1            # a fused descriptor on a ring tile
+
+
+# ---- round 5 ----------------------------------------------------------------------------------------------------------
+def test_status_word_flags_saturation_and_nonfinite_statistics():
+    """r05 (frido_status_flags): an operand producer that clamps a value at +-65504 sets FRIDO_STATUS_SATURATED, a normalisation
+    kernel whose statistics are NaN / inf sets FRIDO_STATUS_NONFINITE; clean work sets nothing; the word is sticky until cleared."""
+    from frido_amd import _lib
+    from frido_amd.engine import plane_dtype
+    from frido_amd.builder import ACT_SILU
+    _lib.status_flags(clear=True)
+    M, K = 256, 64
+    a = _t("st:a", M, K)
+    # clean: pack -> GEMM (operand output) -> GroupNorm -> LayerNorm
+    b = _builder(2, {"w.weight": (_t("st:w", 64, K) / 8).cuda(), "n.weight": torch.ones(64).cuda(), "n.bias": torch.zeros(64).cuda()})
+    ad = a.cuda()
+    a_op = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+    o = b.linear(a_op, "w", bias=False, out="op")
+    f = b.linear(a_op, "w", bias=False)
+    g, _ = b.groupnorm(f, None, 4, 64, "n", 1e-5, act=ACT_SILU)
+    ln = b.layernorm(f, "n")
+    _run(b)
+    assert _lib.status_flags() == 0
+    if plane_dtype(2) == torch.float16:
+        big = a.clone()
+        big[3, 5] = 7.0e4                                              # one value beyond fp16
+        b2 = _builder(2)
+        bd = big.cuda()
+        b2.pack(bd.data_ptr(), 1, M, K, 0, K)
+        _run(b2)
+        assert _lib.status_flags() == _lib.STATUS_SATURATED
+        assert _lib.status_flags() == _lib.STATUS_SATURATED            # sticky
+        with pytest.warns(_lib.FridoNumericsWarning, match="saturated"):
+            assert _lib.warn_on_status("test") == _lib.STATUS_SATURATED
+        assert _lib.status_flags() == 0                                # cleared by the warning helper
+        # a GEMM epilogue producing an operand beyond the range (the GEGLU hidden / Q class of tensors)
+        b3 = _builder(2, {"w.weight": (_t("st:w", 64, K) * 1.0e4).cuda()})
+        a3 = b3.pack(ad.data_ptr(), 1, M, K, 0, K)
+        b3.linear(a3, "w", bias=False, out="op")
+        _run(b3)
+        assert _lib.status_flags(clear=True) & _lib.STATUS_SATURATED
+    # NaN in the stream -> GroupNorm / LayerNorm statistics
+    for kind in ("gn_fused", "gn_apply", "layernorm"):
+        b4 = _builder(2, {"n.weight": torch.ones(64).cuda(), "n.bias": torch.zeros(64).cuda()})
+        HW = 64 if kind == "gn_fused" else 1024
+        x = b4.f32(4 * HW, 64)
+        x.view().copy_(_t("st:x", 4 * HW, 64).cuda())
+        x.view()[5, 7] = float("nan")
+        if kind == "layernorm":
+            b4.layernorm(x, "n")
+        else:
+            b4.groupnorm(x, None, 4, HW, "n", 1e-5)
+        _run(b4)
+        assert _lib.status_flags(clear=True) & _lib.STATUS_NONFINITE, kind
+    assert _lib.status_flags() == 0
+
+
+def test_cross_attention_skips_the_dead_stream_store():
+    """r05 (FridoAttnSmall.skip_act_store): with FF2 + proj_out chained, h3 = attn2(norm2(h2)) + h2 is read only as an operand and through
+    norm3 -- the launch that writes both copies does not store the f32 rows.  The two copies must equal the storing launch's bit for bit."""
+    B, Nq, Nk, d = 16, 256, 26, 576
+    outs = {}
+    for skip in (False, True):
+        b = _builder(2, {"ln.weight": (1 + 0.1 * _t("sk:lw", d)).cuda(), "ln.bias": (0.1 * _t("sk:lb", d)).cuda()})
+        qd, kd, vd = _t("sk:q", B * Nq, d).cuda(), _t("sk:k", B * Nk, d).cuda(), _t("sk:v", B, d, 32).cuda()
+        vd[:, :, Nk:] = 0
+        q = b.pack(qd.data_ptr(), 1, B * Nq, d, 0, d)
+        k = b.pack(kd.data_ptr(), 1, B * Nk, d, 0, d)
+        vT = b.persistent_op(d, 32, batch=B, zero=True)
+        b.pack(vd.data_ptr(), 1, B * d, 32, 0, 32, out=vT)
+        res = b.f32(B * Nq, d)
+        res.view().copy_(_t("sk:r", B * Nq, d).cuda())
+        bias = _t("sk:b", d).cuda()
+        h = b.attention(q, d, k, d, vT, B, Nq, Nk, d, bias_ptr=bias.data_ptr(), residual=res, stream=True, also_op=True,
+                        ln=("ln", 1e-5), stream_dead=skip)
+        assert getattr(h, "stream_skipped", False) == skip and h.op_copy is not None and h.ln_copy is not None
+        h.view().fill_(float("nan"))
+        _run(b)
+        outs[skip] = (h.view().clone(), h.op_copy.to_f32().clone(), h.ln_copy.to_f32().clone())
+    assert torch.isfinite(outs[False][0]).all() and torch.isnan(outs[True][0]).all()
+    assert torch.equal(outs[False][1], outs[True][1]) and torch.equal(outs[False][2], outs[True][2])
+
+
+@pytest.mark.parametrize("C,scale", [(64, 1.0), (192, 0.5), (960, 1.0), (40, 1.0)])
+def test_pack_vector_path_matches_elementwise_split(C, scale):
+    """r05: pack_kernel's 8-channel path (the residual stream as an operand) writes the planes torch's own hi / lo split gives."""
+    from frido_amd.engine import plane_dtype
+    rows = 1000
+    x = _t("pk:x", rows, C) * 3
+    b = _builder(2)
+    xd = x.cuda()
+    o = b.pack(xd.data_ptr(), 1, rows, C, 0, C, scale=scale)
+    _run(b)
+    dt = plane_dtype(2)
+    v = (x * scale).cuda()
+    hi = v.to(dt)
+    lo = (v - hi.float()).to(dt)
+    t = o.buf[: 2 * o.lo * 2].view(dt).view(2, o.lo)
+    Kp = o.K
+    assert torch.equal(t[0, : rows * Kp].view(rows, Kp)[:, :C], hi) and torch.equal(t[1, : rows * Kp].view(rows, Kp)[:, :C], lo)
+    assert float(t[0, : rows * Kp].view(rows, Kp)[:, C:].abs().sum()) == 0.0

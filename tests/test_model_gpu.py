@@ -1050,3 +1050,83 @@ def test_other_configs_at_their_per_gpu_batch(which):
     assert torch.isfinite(zb).all() and worst["latent"] < E2E_X3["latent_rel"] and worst["flips"] <= 1e-4 * ncodes
     if worst["flips"] == 0:
         assert worst["pix"] < E2E_X3["pix_max"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: two REAL ranks of the HIP sampler (r04 verdict, missing 1 / next 6).  No 8-GPU node exists for this builder, so the
+# evidence obtainable is two processes sharing the test box's one GPU: the real sample_images on each rank (contiguous shard,
+# Philox noise keyed by the global sample index, captured graphs, decode to uint8), joined by the pipeline's ONE all-gather
+# (backend gloo, device tensors staged through host -- RCCL has no second device here).
+TWO_RANK_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+from bench import build_model
+from frido_amd import synth
+from frido_amd.pipeline import sample_images, shard_range
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)                     # BOTH ranks on the one GPU of the box
+dev = torch.device("cuda", 0)
+model = build_model("bf16x3", dev)
+total = 4
+lo, hi = shard_range(total, rank, world)
+ctx = torch.from_numpy(synth.seeded_normal("two:ctx", (total, 26, 640))[lo:hi]).to(dev)
+img = sample_images(model, ctx, S=4, eta=1.0, seed=77, sample0=lo, noise="philox", total=total, gather_dtype="uint8")
+# the latents of the same run, joined by the same collective (for the comparison with ONE batch of 4, where a VQ decision is not in the way)
+from frido_amd.samplers import DDIMSampler
+from frido_amd.pipeline import all_gather_images
+unet = model.model.diffusion_model
+z, _ = DDIMSampler(model).sample(S=4, batch_size=hi - lo, shape=(unet.in_channels, unet.image_size, unet.image_size), conditioning=ctx,
+                                 num_stage=unet.num_stage, eta=1.0, verbose=False, noise="philox", seed=77, sample0=lo, log_every_t=10 ** 9)
+zall = all_gather_images(z, total=total)
+torch.cuda.synchronize()
+assert img.shape == (total, 256, 256, 3) and img.dtype == torch.uint8
+if rank == 0:
+    np.save(%(out)r, img.cpu().numpy())
+    np.save(%(out)r + ".z.npy", zall.cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_real_hip_ranks_on_one_gpu_join_to_the_single_process_result(tmp_path):
+    import subprocess
+    import sys
+    from bench import build_model
+    from frido_amd import synth
+    from frido_amd.pipeline import sample_images
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_npy = str(tmp_path / "joined.npy")
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(TWO_RANK_WORKER % dict(repo=repo, out=out_npy))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", str(script)], capture_output=True, text=True, env=env, timeout=1500, cwd=repo)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert run.stdout.count("ok") == 2
+    joined = torch.from_numpy(np.load(out_npy))
+    # single process, (a) shard by shard with the ranks' own batch shapes: the two-process job must reproduce it BIT FOR BIT
+    model = build_model("bf16x3", torch.device("cuda", 0))
+    ctx = torch.from_numpy(synth.seeded_normal("two:ctx", (4, 26, 640))).cuda()
+    kw = dict(S=4, eta=1.0, seed=77, noise="philox", total=4, gather_dtype="uint8")
+    seq = torch.cat([sample_images(model, ctx[lo:hi].contiguous(), sample0=lo, **kw) for lo, hi in ((0, 2), (2, 4))]).cpu()
+    assert torch.equal(joined, seq)
+    # (b) the whole batch in ONE launch sequence (B = 4 selects other tiles / wave counts than B = 2: fp32 summation orders differ): the
+    # latents agree to the parity bound; the uint8 images up to truncation boundaries (and wherever an unconverged DDIM-4 latent sits
+    # on a VQ decision boundary, DESIGN.md section 5 -- reported, not asserted)
+    from frido_amd.samplers import DDIMSampler
+    unet = model.model.diffusion_model
+    zfull, _ = DDIMSampler(model).sample(S=4, batch_size=4, shape=(unet.in_channels, unet.image_size, unet.image_size), conditioning=ctx,
+                                         num_stage=unet.num_stage, eta=1.0, verbose=False, noise="philox", seed=77, sample0=0, log_every_t=10 ** 9)
+    zjoined = torch.from_numpy(np.load(out_npy + ".z.npy"))
+    lat = _rel(zfull, zjoined)
+    full = sample_images(model, ctx, sample0=0, **kw).cpu()
+    diff = (joined.int() - full.int()).abs()
+    share = float((diff > 0).float().mean())
+    print(f"two ranks vs one batch of 4: latent rel {lat:.2e}; uint8 max |diff| {int(diff.max())} code value(s), share of differing values {share:.2e}")
+    assert lat < E2E_X3["latent_rel"]
+    _record("two_ranks_one_gpu/ddim4", dict(bit_identical_to_sequential_shards=True, latent_rel_vs_one_batch=lat,
+                                            uint8_max_diff_vs_one_batch=int(diff.max()), uint8_share_differing=share))
