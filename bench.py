@@ -355,6 +355,9 @@ def main():
                     help="what a step hands back (and, N > 1, all-gathers): the uint8 HWC images of scripts/sample_diffusion.py "
                          "custom_to_np, written by the decoder's last epilogue (default), or decode_first_stage's f32 NCHW tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short passes of BASELINE configs 3 (t2i f16f8, B = 32, PLMS-100 + CFG 1.5) and 5 (512^2, 3 scales, B = 8) "
+                         "that the N = 1 line carries in `extra.other_configs`")
     ap.add_argument("--no-bf16-extra", "--no-parity-mode", dest="no_bf16_extra", action="store_true",
                     help="skip the extra bf16 (throughput-mode) pass at N = 1")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -496,6 +499,9 @@ def main():
             "whole_step": whole_step(args.ddim_steps, total * args.steps / dt, world),
             "loop_only_value": round(total / dt_loop, 4),         # sample_diffusion.py's `throughput`: sampler loop without decode
             "per_rank_ms_per_step": [round(1e3 * t / args.steps, 2) for t in per_rank],
+            # sticky numerics word of the library after all passes (frido_status_flags): 0 = no fp16 operand plane saturated, no
+            # normalisation statistic was NaN / inf anywhere in the timed work
+            "status_flags": _lib.status_flags(),
         }
         if debug_env:
             out["debug_work_skipped"] = True
@@ -522,6 +528,28 @@ def main():
                     break
             out["extra"] = {"bf16_throughput_mode": extra}
             del m1
+        if world == 1 and args.precision == "bf16x3" and not args.no_other_configs and args.batch == 16 and args.ddim_steps == 200:
+            # (r05, r04 verdict weak 11) the other single-GPU workloads of BASELINE.json, timed by THIS command so that the driver's
+            # record holds them: config 3 (t2i f16f8, batch 32, PLMS-100 + CFG 1.5) and config 5's per-GPU shard (512 x 512, three
+            # scales, batch 8, DDIM-200) -- short passes (1 warm + 2 / 1 timed), same arithmetic as `value`; not the headline metric
+            try:
+                del model
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            others = {}
+            for key, modname, kw in (("config3_t2i_f16f8_B32_plms100_cfg1.5", "bench_config3", dict(steps=2, warmup=1)),
+                                     ("config5_512x512_3scale_B8_ddim200", "bench_config5", dict(steps=1, warmup=1))):
+                try:
+                    mod = __import__(modname)
+                    t_o = time.perf_counter()
+                    others[key] = mod.run(precision="bf16x3", **kw)
+                    others[key]["wall_s_incl_build_and_warmup"] = round(time.perf_counter() - t_o, 1)
+                except Exception as e:      # noqa: BLE001  (a failure here must not lose the headline line)
+                    others[key] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            out.setdefault("extra", {})["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             # B in {1, 4} x {8, 16, 32, all physical cores} torch threads; `cores` = the best point's thread count
             try:      # (r05, advisor) a failure of the CPU leg must not lose the GPU measurement above

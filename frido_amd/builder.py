@@ -38,9 +38,10 @@ GN_CONV_PREFER = int(os.environ.get("FRIDO_GN_CONV_PREFER", "256"))      # A/B: 
 
 
 class Builder:
-    def __init__(self, device, nsplit, weights=None, ws_tag=""):
+    def __init__(self, device, nsplit, weights=None, ws_tag="", planes="f16"):
         self.device = torch.device(device)
         self.nsplit = nsplit
+        self.planes = planes            # two-plane element format = which build of the library this builder's programs run on (_lib.use_planes)
         self.ws_tag = ws_tag
         self.w = weights or {}          # name -> f32 tensor on device (reference state_dict naming)
         self.pool = Pool(self.device)
@@ -585,7 +586,7 @@ class Builder:
                 res = self.f32(B * Nq, d)
                 assert residual is None or getattr(residual, "bf16", False) == res.bf16
                 if ln is not None and LN_IN_ATTN and not res.bf16 and self.nsplit == 2 and (
-                        (flash and d in (256, 384)) or (small and B * (Nq // 16) >= 256)):
+                        (flash and self._flash_ln_ok(d)) or (small and B * (Nq // 16) >= 256)):
                     n = self.op(B * Nq, d)
                     kw.update(ln_op=n.ptr, ln_lo=n.lo, ld_ln=d, ln_w=self.bias(ln[0] + ".weight"), ln_b=self.bias(ln[0] + ".bias"),
                               ln_eps=ln[1])
@@ -627,6 +628,11 @@ class Builder:
                        oo_bs=Nq * d, ldoo=d, oo_lo=o.lo)
         p.free()
         return o
+
+    @staticmethod
+    def _flash_ln_ok(d):
+        L = _lib.lib()
+        return bool(L.frido_attn_flash_ln_supported(d)) if hasattr(L, "frido_attn_flash_ln_supported") else d in (256, 384)
 
     def v_transposed(self, x, ldx, wop, B, Nk, d, *, bias_ptr=None, out=None, x_off=0):
         """vT[z][d][Nk_pad] = (W_v @ x[z]^T): the value projection written transposed so that PV is an

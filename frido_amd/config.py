@@ -7,10 +7,19 @@ import os
 PRECISION = os.environ.get("FRIDO_PRECISION", "bf16x3")
 
 
+# "bf16x3_bf16" (r05): the same two-plane arithmetic on the library build whose planes are bf16 pairs (fp32's range, 2^-17 relative):
+#           for checkpoints whose un-normalised operands leave fp16's +-65504 (the status word's FRIDO_STATUS_SATURATED says so).
+
+
 def nsplit(precision=None):
     p = precision or PRECISION
-    if p == "bf16x3":
+    if p in ("bf16x3", "bf16x3_bf16"):
         return 2
     if p == "bf16":
         return 1
-    raise ValueError(f"unknown precision '{p}' (use 'bf16x3' or 'bf16')")
+    raise ValueError(f"unknown precision '{p}' (use 'bf16x3', 'bf16x3_bf16' or 'bf16')")
+
+
+def planes(precision=None):
+    """Two-plane element format the precision keyword selects: which build of the library the model runs on (_lib.use_planes)."""
+    return "bf16" if (precision or PRECISION) == "bf16x3_bf16" else "f16"

@@ -442,9 +442,17 @@ struct FDGeo {
     static constexpr int KPL = BKV * D * 2, VPL = D * BKV * 2;
     static constexpr int KBUF = NS * KPL, VBUF = NS * VPL, TILE = KBUF + VBUF;
     static constexpr int XCH = NW * 64 * 8 * 4;          // partial-score exchange: 8 floats per lane
-    static constexpr int SMEM = TILE + XCH;
+    // K DOUBLE-buffered where it fits (d = 384: 2 x 48 + 48 + 16 = exactly 160 KiB; d = 256): K_{j+1} then streams in during ALL of tile j
+    // instead of having to land inside the 36-MFMA P V phase (measured: the single-buffered form spends ~1.3 us per phase waiting for
+    // the other buffer's 48 KiB -- both phases are shorter than one DMA round trip); only V^T_j's load stays exposed to phase 1
+    static constexpr bool KDB = 2 * KBUF + VBUF + XCH <= 163840;
+    static constexpr int KSTRIDE = KDB ? KBUF : 0;       // byte distance between the two K buffers
+    static constexpr int V0 = (KDB ? 2 : 1) * KBUF;      // V^T tile offset
+    static constexpr int X0 = V0 + VBUF;                 // exchange buffer offset
+    static constexpr int SMEM = X0 + XCH;
     static constexpr int KP = KS * 2, VP = D / 16;       // 1-KiB DMA pieces per plane
     static_assert(KS % 2 == 0 && CTH % 2 == 0 && SMEM <= 163840, "d-split geometry / LDS budget");
+    static_assert(!KDB || KP % NW == 0, "the counted vmcnt wait of the double-buffered form needs every wave to issue the same number of K pieces");
 };
 
 template <int D>
@@ -494,6 +502,7 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
         int key = j * G::BKV + key_l;
         key = key < d.Nk ? key : d.Nk - 1;
         const frido_bf16* src = Kb + (int64_t)key * d.ldk;
+        unsigned char* dst = smem + (j & 1) * G::KSTRIDE;
 #pragma unroll
         for (int i = 0; i < (G::KP + NW - 1) / NW; ++i) {
             const int piece = wave + NW * i;
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.k_lo : 0) + (piece >> 1) * 32),
-                                                     (lptr_t)(smem + p * G::KPL + piece * 1024), 16, 0, 0);
+                                                     (lptr_t)(dst + p * G::KPL + piece * 1024), 16, 0, 0);
             }
         }
     };
@@ -514,16 +523,16 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + (p ? d.vt_lo : 0) + (int64_t)piece * 16 * d.ldvt),
-                                                     (lptr_t)(smem + G::KBUF + p * G::VPL + piece * 1024), 16, 0, 0);
+                                                     (lptr_t)(smem + G::V0 + p * G::VPL + piece * 1024), 16, 0, 0);
             }
         }
     };
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned frag = (unsigned)(r * 64 + ((g ^ ((4 - ((r >> 2) & 3)) & 3)) << 4));
-    const unsigned k_frag = lds0 + frag + (unsigned)(hf * KSH * 2048);               // this wave's k-steps
-    const unsigned v_frag = lds0 + G::KBUF + frag + (unsigned)(hf * CTH * 1024);      // this wave's output channels
-    const unsigned x_mine = lds0 + G::TILE + (unsigned)((wave * 64 + lane) * 32);
-    const unsigned x_peer = lds0 + G::TILE + (unsigned)(((wave ^ 1) * 64 + lane) * 32);
+    const unsigned k_frag0 = lds0 + frag + (unsigned)(hf * KSH * 2048);              // this wave's k-steps (K buffer 0)
+    const unsigned v_frag = lds0 + G::V0 + frag + (unsigned)(hf * CTH * 1024);        // this wave's output channels
+    const unsigned x_mine = lds0 + G::X0 + (unsigned)((wave * 64 + lane) * 32);
+    const unsigned x_peer = lds0 + G::X0 + (unsigned)(((wave ^ 1) * 64 + lane) * 32);
 
     f32x4 o[CTH];
 #pragma unroll
@@ -537,6 +546,10 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();              // K_j visible; every wave has finished tile j - 1 (its V^T reads, its exchange reads)
         issue_v(j);
+        if constexpr (G::KDB) {                    // the other K buffer was last read in phase 1 of tile j - 1
+            if (j + 1 < ntiles) issue_k(j + 1);
+        }
+        const unsigned k_frag = k_frag0 + (unsigned)((j & 1) * G::KSTRIDE);
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
         {
             bf16x8 kf[2][2][NS];                   // [buffer][half][plane]
@@ -572,10 +585,18 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
         asm volatile("ds_write_b128 %0, %1" ::"v"(x_mine), "v"(s0) : "memory");
         asm volatile("ds_write_b128 %0, %1 offset:16" ::"v"(x_mine), "v"(s1) : "memory");
         // ================= phase 2 head: V^T_j and the partner's partials visible =================
-        wait_vmcnt<0>();
+        if constexpr (G::KDB) {
+            // V^T_j's pieces were issued BEFORE K_{j+1}'s: loads retire in order, so the younger K pieces may stay in flight
+            if (j + 1 < ntiles) wait_vmcnt<NS * ((G::KP + NW - 1) / NW)>();
+            else wait_vmcnt<0>();
+        } else {
+            wait_vmcnt<0>();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // every wave has finished reading K_j
-        if (j + 1 < ntiles) issue_k(j + 1);
+        if constexpr (!G::KDB) {
+            if (j + 1 < ntiles) issue_k(j + 1);
+        }
         f32x4 p0, p1;
         asm volatile("ds_read_b128 %0, %1" : "=v"(p0) : "v"(x_peer));
         asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(p1) : "v"(x_peer));
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
     if (ln) {       // (uniform: every wave of the workgroup takes the two exchange barriers)
         // LayerNorm of the stream row: the pair's half-row sums meet in the exchange buffer; mean first, then the centred sum of
         // squares (layernorm_kernel's two passes), both added as half 0 + half 1 so that the two waves hold identical statistics
-        float* xs = reinterpret_cast<float*>(smem + G::TILE);
+        float* xs = reinterpret_cast<float*>(smem + G::X0);
         const float hs = xor_sum(lsum);
         __builtin_amdgcn_s_barrier();              // (every wave is past its last exchange read of the main loop)
         if (g == 0) xs[wave * 16 + r] = hs;
@@ -759,14 +780,19 @@ int flash_launch(const FridoAttnSmall& d, hipStream_t s) {
     return frido_check_launch("attn_flash");
 }
 
+bool flash_dsplit_on() {
+    static const bool on = !(getenv("FRIDO_FLASH_DSPLIT") && atoi(getenv("FRIDO_FLASH_DSPLIT")) == 0);
+    return on;
+}
+
 template <int D>
 int flash_dispatch(const FridoAttnSmall& d, hipStream_t s) {
     if (d.nsplit == 2) {
-        // (r05) two-plane mode: the d-split 8-wave form (two waves per SIMD) wherever its tile + exchange buffer fit the LDS (d <= 512);
+        // (r05) two-plane mode: the d-split 8-wave form (two waves per SIMD) for 256 <= d <= 512 (d = 576 would need exactly the 160 KiB
+        // of a CU and 8 B of scratch: measured SLOWER than the GEMM chain on the 16 x 16 plane it would serve, 43.6 vs 36.4 us, and not kept);
         // FRIDO_FLASH_DSPLIT=0 keeps r04's 4-wave form (A/B switch)
         if constexpr (D >= 256 && D <= 512) {
-            static const bool dsplit = !(getenv("FRIDO_FLASH_DSPLIT") && atoi(getenv("FRIDO_FLASH_DSPLIT")) == 0);
-            if (dsplit) return flash_ds_launch<D>(d, s);
+            if (flash_dsplit_on()) return flash_ds_launch<D>(d, s);
         }
         return flash_launch<D, 2, 4, (D >= 512 ? 2 : 1)>(d, s);   // hi + lo planes of Q and P: one wave per SIMD
     }
@@ -782,6 +808,8 @@ int flash_dispatch(const FridoAttnSmall& d, hipStream_t s) {
 }  // namespace
 
 extern "C" int frido_attn_flash_supported(int32_t dd) { return dd == 128 || dd == 256 || dd == 384 || dd == 512 || dd == 576; }
+// head widths whose two-plane launch can produce the LayerNorm of its stream rows (FridoAttnSmall.ln_op): the workgroup owns whole rows
+extern "C" int frido_attn_flash_ln_supported(int32_t dd) { return dd == 256 || dd == 384 || (flash_dsplit_on() && dd == 512); }
 
 extern "C" int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->Q && d->K && d->VT && (d->out_op || d->out_act), "null pointer");
@@ -794,9 +822,9 @@ extern "C" int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s) {
                   "strides and plane offsets must keep 16-byte alignment");
     FRIDO_REQUIRE(d->nsplit == 1 || d->nsplit == 2, "nsplit must be 1 or 2");
     FRIDO_REQUIRE(!d->skip_act_store, "skip_act_store is served by frido_attn_small only");
-    FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && (d->d == 256 || d->d == 384) && d->ln_w && d->ln_b && (d->ld_ln & 3) == 0 &&
+    FRIDO_REQUIRE(!d->ln_op || (d->out_act && !d->act_bf16 && d->nsplit == 2 && frido_attn_flash_ln_supported(d->d) && d->ln_w && d->ln_b && (d->ld_ln & 3) == 0 &&
                                 (d->ln_lo & 3) == 0),
-                  "ln_op: bf16x3 f32-stream output with d = 256 or 384 (the workgroup owns whole rows), weight and bias given");
+                  "ln_op: bf16x3 f32-stream output with a head width whose workgroup owns whole rows (frido_attn_flash_ln_supported), weight and bias given");
     hipStream_t st = (hipStream_t)s;
     switch (d->d) {
         case 128: return flash_dispatch<128>(*d, st);

@@ -88,14 +88,15 @@ def pack_conv_weight(w4d, nsplit):
 class Graph:
     def __init__(self, handle, keep):
         self.handle, self.keep = handle, keep
+        self.lib = _lib.lib()           # the build that captured the graph (r05: one per plane format) launches and destroys it
 
     def launch(self, stream):
-        _lib.check(_lib.lib().frido_graph_launch(self.handle, stream), "frido_graph_launch")
+        _lib.check(self.lib.frido_graph_launch(self.handle, stream), "frido_graph_launch")
 
     def __del__(self):
         try:
             if self.handle:
-                _lib.lib().frido_graph_destroy(self.handle)
+                self.lib.frido_graph_destroy(self.handle)
         except Exception:
             pass
 

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import config, holders, schedules
+from . import _lib, config, holders, schedules
 from ._lib import FridoHipError
 
 try:  # pytorch-lightning is optional (absent in this image): keep the LightningModule base when it exists
@@ -280,7 +280,10 @@ class BERTEmbedder(_Versioned, nn.Module):
         self._rt = None
         self._plans = {}
 
+    planes = property(lambda self: config.planes(self.precision))      # which build of the library (_lib.use_planes)
+
     @torch.no_grad()
+    @_lib.with_planes
     def forward(self, text, return_token=False):
         tokens = text[self.cond_key] if self.cond_key != "" else text
         if not torch.is_tensor(tokens):       # captions as strings (use_tokenizer=True configs): encoders/modules.py:63-64,99-104
@@ -297,7 +300,7 @@ class BERTEmbedder(_Versioned, nn.Module):
         from .runtime import _weights_of
         if self._rt is None:
             require_gpu(dev)
-            self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev))
+            self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev), planes=config.planes(self.precision))
         plan = _cached_plan(self._plans, (B, n), self._rt, lambda: BertPlan(self._rt, B=B, n=n, dim=self.n_embed, depth=self.n_layer,
                                                                             vocab=self.vocab_size))
         plan.tokens.copy_(tokens.reshape(-1))
@@ -376,7 +379,10 @@ class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
                 "package is not reachable offline -- pass token ids ([B, 77] int64), a tokenizer= callable, or the finished "
                 "[B, n_repeat, embed_dim] embedding to the sampler as `conditioning`") from None
 
+    planes = property(lambda self: config.planes(self.precision))
+
     @torch.no_grad()
+    @_lib.with_planes
     def forward(self, text):
         tokens = self._tokens(text)
         dev = next(self.parameters()).device
@@ -392,7 +398,7 @@ class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
         from .runtime import _weights_of
         if self._rt is None:
             require_gpu(dev)
-            self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev))
+            self._rt = Builder(dev, config.nsplit(self.precision), _weights_of(self, dev), planes=config.planes(self.precision))
         plan = _cached_plan(self._plans, (B, n), self._rt, lambda: ClipTextPlan(self._rt, B=B, n=n, width=width, layers=layers, heads=heads,
                                                                                 vocab=vocab, embed_dim=embed_dim, normalize=self.normalize))
         plan.tokens.copy_(tokens.reshape(-1))

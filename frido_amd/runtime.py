@@ -31,10 +31,12 @@ def _run1(builder, kind, stream, **kw):
 
 class DenoiserRuntime:
     def __init__(self, module, cfg, device, precision=None):
-        self.device = require_gpu(device)
+        self.planes = config.planes(precision)      # (r05) which build of the library this model runs on: see _lib.use_planes
+        with _lib.use_planes(self.planes):
+            self.device = require_gpu(device)
         self.cfg = cfg
         self.nsplit = config.nsplit(precision)
-        self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
+        self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device), planes=self.planes)
         self.plans = {}
         self._replicas = {0: self.b}
 
@@ -44,9 +46,10 @@ class DenoiserRuntime:
         captured step bodies can be replayed CONCURRENTLY on different streams (only tools/dual_stream_exp.py does that: the
         measured gain of two concurrent sub-batches was +1 %, so pipeline.sample_images runs ONE replica)."""
         if replica not in self._replicas:
-            self._replicas[replica] = Builder(self.device, self.nsplit, self.b.w, ws_tag=f":r{replica}")
+            self._replicas[replica] = Builder(self.device, self.nsplit, self.b.w, ws_tag=f":r{replica}", planes=self.planes)
         return self._replicas[replica]
 
+    @_lib.with_planes
     def forward(self, x, t, context, stage):
         """x (B, Cin, H, W) f32 cuda NCHW, t (B,) int64, context (B, nctx, cd) -> eps (B, nch, H, W)."""
         B, Cin, H, W = x.shape
@@ -75,8 +78,13 @@ class DenoiserRuntime:
 class SamplerEngine:
     """One instance per (denoiser weights, B, latent shape, context length, S, eta, cfg on/off, kind)."""
 
-    def __init__(self, builder: Builder, cfg, *, B, C, H, W, nctx, S, eta, kind, alphas_cumprod, embed_dim, cfg_scale=1.0,
-                 use_graph=True, num_stage=None, temperature=1.0):
+    def __init__(self, builder: Builder, cfg, **kw):
+        self.planes = builder.planes
+        with _lib.use_planes(self.planes):
+            self._init(builder, cfg, **kw)
+
+    def _init(self, builder: Builder, cfg, *, B, C, H, W, nctx, S, eta, kind, alphas_cumprod, embed_dim, cfg_scale=1.0,
+              use_graph=True, num_stage=None, temperature=1.0):
         self.b, self.cfg = builder, cfg
         self.dev = builder.device
         self.B, self.C, self.H, self.W, self.nctx = B, C, H, W, nctx
@@ -159,6 +167,7 @@ class SamplerEngine:
 
     # ---- main entry --------------------------------------------------------------------------------
     @torch.no_grad()
+    @_lib.with_planes
     def run(self, cond, uncond=None, *, x_T=None, noise="philox", seed=0, sample0=0, log_every_t=100, callback=None,
             img_callback=None, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None, model=None):
         """Runs all stages.  noise: "philox" (device counter RNG), "torch" (draw from torch's global CPU generator in
@@ -432,14 +441,17 @@ class SamplerEngine:
 
 class DecoderRuntime:
     def __init__(self, module, vq_cfg, device, precision=None):
-        self.device = require_gpu(device)
+        self.planes = config.planes(precision)
+        with _lib.use_planes(self.planes):
+            self.device = require_gpu(device)
         self.cfg = vq_cfg
         self.nsplit = config.nsplit(precision)
-        self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device))
+        self.b = Builder(self.device, self.nsplit, _weights_of(module, self.device), planes=self.planes)
         self.plans = {}
 
     U8_MODES = {False: 0, None: 0, True: 1, "np": 1, "pil": 2}
 
+    @_lib.with_planes
     def decode(self, z, inv_scale=None, return_code=False, to_uint8=False, force_codes=None):
         """z (B, Ctot, h, w) NCHW latent -> image (B, 3, H, W); inv_scale: per-scale multiplier (1/scale_factor).
         to_uint8: True / "np" -> the (B, H, W, 3) uint8 array of scripts/sample_diffusion.py:115-121 (custom_to_np), "pil" -> the
@@ -473,6 +485,7 @@ class DecoderRuntime:
             return out, [i.view(B, -1) for i in plan.idx]
         return out
 
+    @_lib.with_planes
     def encode(self, x, scale=None):
         """x (B, 3, H, W) NCHW image -> pre-quantisation latent (B, sum(embed), H/f, W/f); `scale` (per scale) folds
         get_first_stage_encoding's multiply in."""

@@ -41,7 +41,7 @@ def _lib_tag():
     mode = f"+sk{SK_MODE}" if SK_MODE else ""       # tiles tuned under another split-K reduction are not comparable
     try:
         import hashlib
-        with open(_lib.LIB_PATH, "rb") as f:      # content hash: two builds of equal size must not share pinned tiles
+        with open(_lib.LIB_PATHS[_lib.active_planes()], "rb") as f:      # content hash: two builds of equal size must not share pinned tiles
             return hashlib.sha256(f.read()).hexdigest()[:16] + mode
     except OSError:
         return "?"
@@ -65,7 +65,7 @@ def _save_cache():
         # (one writer under torch.distributed.run; bench.py reads the tracked cache and only rewrites it under --retune)
         tmp = f"{CACHE_FILE}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
-            json.dump({"lib": _lib_tag(), "entries": [[list(k), list(v)] for k, v in _cache.items()]}, f)
+            json.dump({"lib": _lib_tag(), "entries": [[list(k), list(v)] for k, v in _cache.items() if not isinstance(k[-1], str)]}, f)
         os.replace(tmp, CACHE_FILE)
 
 
@@ -118,6 +118,8 @@ def best_tile(st, device, stream):
         return 0, 1
     sig = tuple(getattr(st, f) for f in _SIG_FIELDS) + (bool(st.residual), bool(st.out_f32), bool(st.out_op),
                                                         bool(st.bias), bool(st.rowvec), bool(st.row_bias))
+    if _lib.active_planes() != "f16":      # (r05) the bf16-pair build: its own choices, never persisted (the pinned cache file is the default build's)
+        sig = sig + (_lib.active_planes(),)
     if sig in _cache:
         return _cache[sig]
     if ON_MISS == "static":
@@ -204,5 +206,6 @@ def best_tile(st, device, stream):
                 best, best_t = (tile, sk), dt
     _cache[sig] = best
     global _dirty
-    _dirty = True
+    if _lib.active_planes() == "f16":
+        _dirty = True
     return best

@@ -424,6 +424,9 @@ int frido_l2norm(const FridoL2Norm* d, frido_stream_t s);
  * 512^2).  frido_attn_flash_supported(d) tells whether a head dimension is instantiated. */
 int frido_attn_flash(const FridoAttnSmall* d, frido_stream_t s);
 int frido_attn_flash_supported(int32_t d);
+/* (r05) head widths for which a two-plane frido_attn_flash launch may carry FridoAttnSmall.ln_op (its workgroups own whole rows):
+ * 256 and 384 always, 512 on the d-split 8-wave form (the default; FRIDO_FLASH_DSPLIT=0 selects the 4-wave form). */
+int frido_attn_flash_ln_supported(int32_t d);
 /* One-launch GroupNorm (statistics + apply) on a FridoGnApply descriptor whose `partials` is unused; bf16 stream only.
  * frido_gn_fused_chunk returns the channel-chunk width it would use (and the workgroup size), or 0 if the descriptor does
  * not qualify -- then gn_stats + gn_apply is the path. */

@@ -37,15 +37,21 @@ from golden_cfg import (UNET_SMALL, UNET_FULL, VQ_SMALL, VQ_FULL, UNET_SMALL3, V
                         frido_cfg, BERT_FULL, UNET_F16F8, VQ_F16F8, UNET_512, VQ_512)
 
 
+PROFILE = None       # --profile heavy: the trained-checkpoint-like filler (frido_amd/synth.py _fill_heavy); fixtures get the suffix _heavy
+
+
 def fill_module(mod, prefix=""):
     """Fill every parameter/buffer-free weight of `mod` from the deterministic filler."""
     with torch.no_grad():
         for name, p in mod.named_parameters():
-            p.copy_(torch.from_numpy(fill_tensor(prefix + name, p.shape)))
+            p.copy_(torch.from_numpy(fill_tensor(prefix + name, p.shape, PROFILE)))
     return mod
 
 
 def save(name, **arrs):
+    if PROFILE:
+        name = f"{name}_{PROFILE}"
+        arrs["filler_profile"] = np.array(PROFILE)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
@@ -110,10 +116,15 @@ def gen_unet(tag, cfg, B, nctx, hw, capture=True):
             hooks.append(net.middle_block.register_forward_hook(mk("mid")))
             hooks.append(net.pre_input_blocks[s].register_forward_hook(mk("pre")))
             hooks.append(net.output_blocks[-1].register_forward_hook(mk("ob_last")))
+        smax = [0.0]
+        for blk in list(net.input_blocks) + [net.middle_block] + list(net.output_blocks):
+            hooks.append(blk.register_forward_hook(lambda m, i, o, smax=smax: smax.__setitem__(0, max(smax[0], float(o.detach().abs().max())))))
         with torch.no_grad():
             e = net(xin, t, context=ctx, stage=s)
         for h in hooks:
             h.remove()
+        out[f"stream_absmax_{s}"] = np.float64(smax[0])
+        print(f"  stage {s}: residual stream max |x| = {smax[0]:.4g}, eps max {float(e.abs().max()):.4g}")
         out[f"t_{s}"] = t.numpy()
         out[f"eps_{s}"] = e.numpy()
         for k, v in caps.items():
@@ -187,6 +198,16 @@ class NoiseTape:
         torch.randn = self._orig
 
 
+_STREAM_MAX = [0.0]
+
+
+def _watch_stream(model):
+    """running max |x| over the outputs of every U-Net block (what the raw-stream operand producers of the HIP path see)"""
+    net = model.model.diffusion_model
+    for blk in list(net.input_blocks) + [net.middle_block] + list(net.output_blocks):
+        blk.register_forward_hook(lambda m, i, o: _STREAM_MAX.__setitem__(0, max(_STREAM_MAX[0], float(o.detach().abs().max()))))
+
+
 def build_frido(ucfg, vcfg, bcfg):
     fr = H.import_ref("frido.models.diffusion.frido")
     H.patch_samplers()
@@ -198,6 +219,7 @@ def build_frido(ucfg, vcfg, bcfg):
     fill_module(model.first_stage_model, "first_stage_model.")
     fill_module(model.cond_stage_model, "cond_stage_model.")
     model.scale_factor.copy_(torch.tensor([0.9, 1.1, 1.05][:len(vcfg["embed_dim"])]))
+    _watch_stream(model)
     return model.eval()
 
 
@@ -248,6 +270,8 @@ def gen_sampler(tag, ucfg, vcfg, bcfg, B, nctx):
     out["step_xprev"] = xp.numpy()
     out["step_predx0"] = px0.numpy()
     out["step_noise"] = tape.draws[0]
+    out["stream_absmax"] = np.float64(_STREAM_MAX[0])
+    print(f"  residual stream max |x| over all runs = {_STREAM_MAX[0]:.4g}")
     save(tag, **out)
 
 
@@ -362,7 +386,9 @@ def gen_sampler_full():
         c = model.get_learned_conditioning(tokens)
     out = {"tokens": tokens.numpy(), "c": c.numpy(), "scale_factor": model.scale_factor.numpy()}
     _run_sampler(out, model, "ddim4", DDIM, 4, 1.0, 1.0, c, None, (6, 64, 64), 2, 2, 4)
-    _run_sampler(out, model, "ddim50", DDIM, 50, 1.0, 1.0, c, None, (6, 64, 64), 2, 10, 4)
+    if not PROFILE:      # (the heavy-profile fixture keeps the 8 forwards of DDIM-4: the dynamic range is the point, not the step count)
+        _run_sampler(out, model, "ddim50", DDIM, 50, 1.0, 1.0, c, None, (6, 64, 64), 2, 10, 4)
+    out["stream_absmax"] = np.float64(_STREAM_MAX[0])
     save("sampler_full", **out)
 
 
@@ -531,6 +557,10 @@ GENS = {
 }
 
 if __name__ == "__main__":
+    if "--profile" in sys.argv:
+        i = sys.argv.index("--profile")
+        PROFILE = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     names = sys.argv[1:] or list(GENS)
     torch.set_num_threads(8)
     for n in names:

@@ -15,9 +15,9 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
-def synth_sd(module: nn.Module, prefix):
-    """{prefix+name: filler tensor} for every parameter of a holder tree."""
-    return {prefix + k: torch.from_numpy(fill_tensor(prefix + k, v.shape)) for k, v in module.state_dict().items()}
+def synth_sd(module: nn.Module, prefix, profile=None):
+    """{prefix+name: filler tensor} for every parameter of a holder tree (profile: frido_amd.synth filler profile)."""
+    return {prefix + k: torch.from_numpy(fill_tensor(prefix + k, v.shape, profile)) for k, v in module.state_dict().items()}
 
 
 def unet_holder(cfg):

@@ -901,7 +901,7 @@ def _bench_ctx(B):
     return torch.from_numpy(seeded_normal("bench:ctx", (B, 26, 640)))
 
 
-@pytest.mark.parametrize("B,S,rows", [(16, 50, (0, 7, 15)), (32, 20, (0, 31))], ids=["config2_B16", "config4_shard_B32"])
+@pytest.mark.parametrize("B,S,rows", [(16, 200, (0, 7, 15)), (32, 20, (0, 31))], ids=["config2_B16_ddim200", "config4_shard_B32"])
 def test_benchmarked_batch_rows_equal_single_sample_runs(B, S, rows):
     """BASELINE config 2 (B = 16) and config 4's per-GPU shard (B = 32) at full width: the Philox noise is keyed by the GLOBAL sample
     index, so row i of the batched run must reproduce the B = 1 run with sample0 = i -- whose arithmetic the B = 1 goldens pin to
@@ -924,6 +924,25 @@ def test_benchmarked_batch_rows_equal_single_sample_runs(B, S, rows):
     print(f"B = {B} vs B = 1 rows {rows}: {worst}")
     _record(f"batch{B}/rows_vs_b1/ddim{S}", worst)
     assert worst["latent"] < E2E_X3["latent_rel"] and worst["flips"] == 0 and worst["pix"] < E2E_X3["pix_max"]
+    if B == 16:
+        # (r05, r04 verdict weak 1) the BATCHED decode directly against the oracle (CPU restatement pinned to the reference) on the HIP
+        # path's own latent: the B = 16 decoder tiles (M = 16 x 65536) meet a reference implementation without going through B = 1 --
+        # all 2 x 16 x 4096 codes exactly, every pixel of the 16 images to the parity bound
+        from oracle import samplers as OS
+        from oracle.vqgan import vq_decode
+        vsd = synth_sd(vq_holder(VQ_FULL), "first_stage_model.")
+        keep = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        try:
+            ref_img, ref_codes = OS.decode_first_stage(lambda zz: vq_decode(vsd, VQ_FULL, zz, return_code=True), zb.cpu(),
+                                                       [float(v) for v in model.scale_factor.cpu()], [3, 3])
+        finally:
+            torch.set_num_threads(keep)
+        code_diff = int(sum((ref_codes[i].reshape(B, -1).numpy() != cb[i].reshape(B, -1)).sum() for i in range(2)))
+        pix = float((ib.cpu() - ref_img).abs().max())
+        print(f"B = 16 decode vs the oracle on the HIP latent: {code_diff} of {2 * B * 4096} codes differ, pixels max-abs {pix:.2e}")
+        _record("batch16/decode_vs_oracle", dict(codes_differing=code_diff, codes_total=2 * B * 4096, pix_max=pix))
+        assert code_diff == 0 and pix < E2E_X3["pix_max"]
 
 
 @pytest.mark.parametrize("B", [16, 32])
@@ -1130,3 +1149,131 @@ def test_two_real_hip_ranks_on_one_gpu_join_to_the_single_process_result(tmp_pat
     assert lat < E2E_X3["latent_rel"]
     _record("two_ranks_one_gpu/ddim4", dict(bit_identical_to_sequential_shards=True, latent_rel_vs_one_batch=lat,
                                             uint8_max_diff_vs_one_batch=int(diff.max()), uint8_share_differing=share))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: parity under a TRAINED-CHECKPOINT-LIKE dynamic range (r04 verdict, weak 2 / next 5).  Every fixture above fills weights
+# with the fan-in-scaled N(0, sigma) filler; these use frido_amd.synth's "heavy" profile (heavy-tailed weights, norm scales in
+# [0.2, 3], 0.5-sigma biases, residual-branch gains that put the raw stream in the thousands) -- fixtures captured from the reference
+# with it (tests/golden/make_golden.py --profile heavy) -- on BOTH plane formats of the two-plane arithmetic: fp16 pairs
+# (precision "bf16x3", 2^-22 relative, |v| <= 65504) and bf16 pairs ("bf16x3_bf16", 2^-17, fp32's range).
+PLANE_PRECISIONS = ["bf16x3", "bf16x3_bf16"]
+
+
+def _heavy_unet(cfg, precision):
+    from frido_amd.models import PyUNetModel
+    return fill_module(PyUNetModel(**cfg, precision=precision), "model.diffusion_model.", "heavy").cuda().eval()
+
+
+@pytest.mark.parametrize("precision", PLANE_PRECISIONS)
+@pytest.mark.parametrize("name,cfg", [("unet_small_heavy", UNET_SMALL), ("unet_full_heavy", UNET_FULL)])
+def test_unet_forward_heavy_profile_both_plane_formats(name, cfg, precision):
+    from frido_amd import _lib
+    g = golden(name)
+    _lib.status_flags(clear=True)
+    m = _heavy_unet(cfg, precision)
+    x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    errs = []
+    for s in range(2):
+        e = m(x[:, :3 * (s + 1)].contiguous(), torch.from_numpy(g[f"t_{s}"]).cuda(), context=ctx, stage=s)
+        errs.append(_rel(e, g[f"eps_{s}"]))
+    flags = _lib.status_flags(clear=True)
+    print(f"{name} [{precision}]: eps rel err {errs[0]:.2e} / {errs[1]:.2e}, reference stream max {float(g['stream_absmax_1']):.3g}, status flags {flags}")
+    _record(f"heavy/{name}/{precision}", dict(eps_rel_stage0=errs[0], eps_rel_stage1=errs[1], stream_absmax=float(g["stream_absmax_1"]), status_flags=flags))
+    assert flags == 0                                   # the stream stays inside fp16's range on these fixtures: nothing may saturate
+    assert max(errs) < (2e-4 if precision == "bf16x3" else 2e-3)      # same bound as the default-filler fixtures; the 16-bit-mantissa pairs get 10x
+
+
+@pytest.mark.parametrize("precision", PLANE_PRECISIONS)
+@pytest.mark.parametrize("name,cfg", [("vq_small_heavy", VQ_SMALL), ("vq_full_heavy", VQ_FULL)])
+def test_vq_decode_heavy_profile_both_plane_formats(name, cfg, precision):
+    from frido_amd.models import VQModelInterface
+    from frido_amd import _lib
+    g = golden(name)
+    _lib.status_flags(clear=True)
+    m = fill_module(VQModelInterface(**cfg, lossconfig=dict(target="taming.modules.losses.DummyLoss"), precision=precision),
+                    "first_stage_model.", "heavy").cuda().eval()
+    h = torch.from_numpy(g["h"]).cuda()
+    ss = int(g["subsample"])
+    dec, code = m.decode(h, return_code=True)
+    flips = float((np.asarray(code) != g["code"]).mean())
+    forced = m.decode(h, force_codes=[g["code"][i] for i in range(len(cfg["embed_dim"]))])
+    r = _rel(forced[:, :, ::ss, ::ss], g["dec"])
+    flags = _lib.status_flags(clear=True)
+    print(f"{name} [{precision}]: VQ code flips {flips:.2e}, decoder rel err on the reference's codes {r:.2e}, status flags {flags}")
+    _record(f"heavy/{name}/{precision}", dict(vq_flip_rate=flips, forced_decoder_rel=r, status_flags=flags))
+    assert flips == 0 and flags == 0
+    assert r < (2e-4 if precision == "bf16x3" else 2e-3)
+
+
+@pytest.mark.parametrize("precision", PLANE_PRECISIONS)
+@pytest.mark.parametrize("run", ["ddim_eta1", "plms_cfg"])
+def test_sampler_heavy_profile_both_plane_formats(run, precision):
+    from frido.models.diffusion.ddim import DDIMSampler
+    from frido.models.diffusion.plms import PLMSSampler
+    from frido_amd.models import instantiate_from_config
+    from frido_amd import _lib
+    g = golden("sampler_small_heavy")
+    cfg = frido_cfg(dict(UNET_SMALL, precision=precision), dict(VQ_SMALL, precision=precision), BERT_SMALL)
+    cfg["cond_stage_config"], cfg["conditioning_key"] = "__is_unconditional__", "crossattn"
+    model = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+    fill_module(model.model, "model.", "heavy")
+    fill_module(model.first_stage_model, "first_stage_model.", "heavy")
+    model.scale_factor.copy_(torch.tensor([0.9, 1.1]))
+    model = model.cuda().eval()
+    _lib.status_flags(clear=True)
+    c = torch.from_numpy(g["c"]).cuda()
+    S, eta, scale, lev = g[f"{run}_args"]
+    cls = PLMSSampler if run.startswith("plms") else DDIMSampler
+    tape = _Tape(g[f"{run}_noise"])
+    samples, _ = cls(model).sample(S=int(S), batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=float(eta), verbose=False,
+                                   log_every_t=int(lev), unconditional_guidance_scale=float(scale),
+                                   unconditional_conditioning=torch.zeros_like(c) if scale != 1.0 else None, noise=tape)
+    lat = _rel(samples, g[f"{run}_samples"])
+    flags = _lib.status_flags(clear=True)
+    print(f"sampler_small_heavy/{run} [{precision}]: latent rel err {lat:.2e} (reference stream max {float(g['stream_absmax']):.3g}), status flags {flags}")
+    _record(f"heavy/sampler_small_heavy/{run}/{precision}", dict(latent_rel=lat, stream_absmax=float(g["stream_absmax"]), status_flags=flags))
+    assert tape.pos == tape.t.numel()
+    assert flags & _lib.STATUS_NONFINITE == 0
+    assert lat < (1e-3 if precision == "bf16x3" else 5e-3)
+
+
+def test_full_size_heavy_sampler_saturates_fp16_planes_and_runs_on_bf16_pairs():
+    """sampler_full_heavy: DDIM-4 at full width with the heavy filler -- a random-weight denoiser does not denoise, x grows to ~100 and
+    the reference's raw residual stream reaches 7e5: BEYOND fp16.  The default (fp16-pair) arithmetic must SAY so (status word ->
+    FridoNumericsWarning); the bf16-pair build of the same kernels -- a per-model runtime choice -- runs it at its own error level."""
+    from frido.models.diffusion.ddim import DDIMSampler
+    from frido_amd.models import instantiate_from_config
+    from frido_amd import _lib
+    from frido_amd.pipeline import sample_images  # noqa: F401  (the warning helper lives in _lib)
+    g = golden("sampler_full_heavy")
+    assert float(g["stream_absmax"]) > 65504.0
+    c = torch.from_numpy(g["c"]).cuda()
+    out = {}
+    for precision in PLANE_PRECISIONS:
+        cfg = frido_cfg(dict(UNET_FULL, precision=precision), dict(VQ_FULL, precision=precision), BERT_SMALL)
+        cfg["cond_stage_config"], cfg["conditioning_key"] = "__is_unconditional__", "crossattn"
+        model = instantiate_from_config(dict(target="frido.models.diffusion.frido.FridoDiffusion", params=cfg))
+        fill_module(model.model, "model.", "heavy")
+        fill_module(model.first_stage_model, "first_stage_model.", "heavy")
+        model.scale_factor.copy_(torch.from_numpy(g["scale_factor"]))
+        model = model.cuda().eval()
+        _lib.status_flags(clear=True)
+        torch.manual_seed(23)
+        samples, _ = DDIMSampler(model).sample(S=4, batch_size=1, shape=(6, 64, 64), conditioning=c, num_stage=2, eta=1.0, verbose=False,
+                                               log_every_t=2, noise="torch")
+        lat = _rel(samples, g["ddim4_samples"])
+        flags = _lib.status_flags()
+        out[precision] = (lat, flags)
+        print(f"sampler_full_heavy [{precision}]: latent rel err {lat:.2e}, status flags {flags} (reference stream max {float(g['stream_absmax']):.3g})")
+        _record(f"heavy/sampler_full_heavy/ddim4/{precision}", dict(latent_rel=lat, status_flags=flags, stream_absmax=float(g["stream_absmax"])))
+        if precision == "bf16x3":
+            assert flags & _lib.STATUS_SATURATED
+            with pytest.warns(_lib.FridoNumericsWarning, match="saturated"):
+                _lib.warn_on_status("sampler_full_heavy")
+        else:
+            assert flags == 0
+            _lib.status_flags(clear=True)
+        del model
+        torch.cuda.empty_cache()
+    assert out["bf16x3_bf16"][0] < 5e-3

@@ -272,3 +272,29 @@ def test_sampler_options_oracle_bit_exact():
         out, inter = S.plms_sample(am, ac, 6, (2, 6, 16, 16), c, [3, 3], [3, 3], 2, log_every_t=2, **kw)
         assert torch.equal(out, torch.from_numpy(g[f"{name}_samples"])), name
         assert torch.equal(inter["pred_x0"][1], torch.from_numpy(g[f"{name}_pred_x0_1"])) and len(inter["x_inter"]) == int(g[f"{name}_nx"])
+
+
+# ---- round 5: the same pins under a trained-checkpoint-like dynamic range (frido_amd/synth.py profile "heavy": heavy-tailed weights,
+#      GroupNorm / LayerNorm scales in [0.2, 3], 0.5-sigma biases, a residual stream in the thousands) --------------------------------
+def test_oracle_heavy_profile_unet_vq_sampler():
+    g = golden("unet_small_heavy")
+    assert str(g["filler_profile"]) == "heavy" and 1.0e3 < float(g["stream_absmax_1"]) < 6.0e4
+    sd = synth_sd(unet_holder(UNET_SMALL), "model.diffusion_model.", "heavy")
+    x, ctx = torch.from_numpy(g["x"]), torch.from_numpy(g["ctx"])
+    for s in range(2):
+        e = unet_forward(sd, UNET_SMALL, x[:, :3 * (s + 1)], torch.from_numpy(g[f"t_{s}"]), ctx, s)
+        assert torch.equal(e, torch.from_numpy(g[f"eps_{s}"])), s
+    gv = golden("vq_small_heavy")
+    vsd = synth_sd(vq_holder(VQ_SMALL), "first_stage_model.", "heavy")
+    dec, codes = vq_decode(vsd, VQ_SMALL, torch.from_numpy(gv["h"]), return_code=True)
+    assert all(np.array_equal(c.numpy(), gv["code"][i]) for i, c in enumerate(codes))
+    assert float((dec - torch.from_numpy(gv["dec"])).abs().max()) < 1e-5 * max(1.0, float(np.abs(gv["dec"]).max()))
+    gs = golden("sampler_small_heavy")
+    ac = S.alphas_cumprod_f32(S.make_betas())
+    c = torch.from_numpy(gs["c"])
+    am = lambda xx, t, cond, s: unet_forward(sd, UNET_SMALL, xx, t, cond, s)
+    for run, fn, kw in [("ddim_eta1", S.ddim_sample, dict(eta=1.0)), ("plms_cfg", S.plms_sample, {})]:
+        Sx, eta, scale, lev = gs[f"{run}_args"]
+        out, _ = fn(am, ac, int(Sx), (2, 6, 16, 16), c, [3, 3], [3, 3], 2, scale=float(scale), uc=torch.zeros_like(c),
+                    noise=S.NoiseSource(gs[f"{run}_noise"]), log_every_t=int(lev), **kw)
+        assert torch.equal(out, torch.from_numpy(gs[f"{run}_samples"])), run

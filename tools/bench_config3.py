@@ -18,15 +18,23 @@ from frido_amd import configs, synth  # noqa: E402
 from frido_amd.engine import require_gpu  # noqa: E402
 
 
-def main():
+def _args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])      # bf16x3 = the arithmetic of the parity tests
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--plms-steps", type=int, default=100)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    args = ap.parse_args()
-    dev = require_gpu("cuda:0")
+    return ap.parse_args(argv)
+
+
+def run(**kw):
+    """The measurement as a function (bench.py calls it for its `extra` block): keyword overrides of the CLI defaults -> result dict."""
+    args = _args([])
+    for k, v in kw.items():
+        assert hasattr(args, k), k
+        setattr(args, k, v)
+    dev = require_gpu(f"cuda:{torch.cuda.current_device()}")
     from frido_amd.models import instantiate_from_config
     from frido_amd.samplers import PLMSSampler
     cfg = configs.frido_cfg(configs.UNET_F16F8, configs.VQ_F16F8, configs.BERT_FULL)
@@ -61,12 +69,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert img.shape[0] == B and bool(torch.isfinite(img).all())
-    print(json.dumps({"metric": f"images/sec @ PLMS-{args.plms_steps} + CFG 1.5, COCO text2img 256x256 (BASELINE config 3)",
+    return {"metric": f"images/sec @ PLMS-{args.plms_steps} + CFG 1.5, COCO text2img 256x256 (BASELINE config 3)",
                       "value": round(B * args.steps / dt, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "dtype": args.precision,
                       "data": "synthetic (random-init weights, N(0,1) context tokens, Philox x_T)",
                       "config": {"workload": f"t2i f16f8, batch {B}, PLMS-{args.plms_steps} x {unet.num_stage} stages, CFG 1.5 "
-                                             f"(cond + uncond batched: {2 * B} rows per forward), image {tuple(img.shape[1:])}"}}))
+                                             f"(cond + uncond batched: {2 * B} rows per forward), image {tuple(img.shape[1:])}"}}
+
+
+def main():
+    print(json.dumps(run(**vars(_args()))))
 
 
 if __name__ == "__main__":

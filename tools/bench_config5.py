@@ -18,15 +18,23 @@ from frido_amd import configs, synth  # noqa: E402
 from frido_amd.engine import require_gpu  # noqa: E402
 
 
-def main():
+def _args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])      # bf16x3 = the arithmetic of the parity tests
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--ddim-steps", type=int, default=200)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    args = ap.parse_args()
-    dev = require_gpu("cuda:0")
+    return ap.parse_args(argv)
+
+
+def run(**kw):
+    """The measurement as a function (bench.py calls it for its `extra` block): keyword overrides of the CLI defaults -> result dict."""
+    args = _args([])
+    for k, v in kw.items():
+        assert hasattr(args, k), k
+        setattr(args, k, v)
+    dev = require_gpu(f"cuda:{torch.cuda.current_device()}")
     from frido_amd.models import instantiate_from_config
     from frido_amd.pipeline import sample_images
     cfg = configs.frido_cfg(configs.UNET_512, configs.VQ_512, configs.BERT_FULL)
@@ -55,13 +63,17 @@ def main():
     dt = time.perf_counter() - t0
     assert tuple(img.shape) == (B, 3, 512, 512) and bool(torch.isfinite(img).all())
     unet = model.model.diffusion_model
-    print(json.dumps({"metric": f"images/sec @ DDIM-{args.ddim_steps}, layout2img 512x512, 3-scale pyramid (BASELINE config 5)",
+    return {"metric": f"images/sec @ DDIM-{args.ddim_steps}, layout2img 512x512, 3-scale pyramid (BASELINE config 5)",
                       "value": round(B * args.steps / dt, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "dtype": args.precision,
                       "data": "synthetic (random-init weights, N(0,1) context, Philox x_T / noise)",
                       "config": {"workload": f"9 x 128 x 128 latent, {unet.num_stage} stages x DDIM-{args.ddim_steps} eta=1.0, per-GPU batch {B}, "
                                              "512 x 512 MS-VQGAN decode (attention over 16384 keys)",
-                                 "denoiser_forwards_per_step": unet.num_stage * args.ddim_steps}}))
+                                 "denoiser_forwards_per_step": unet.num_stage * args.ddim_steps}}
+
+
+def main():
+    print(json.dumps(run(**vars(_args()))))
 
 
 if __name__ == "__main__":
