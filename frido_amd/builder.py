@@ -495,6 +495,16 @@ class Builder:
         """GroupNorm(32) [+SPADE] [+SiLU] of the (virtually concatenated) NHWC f32 input -> operand.  x1_dead: nothing after this
         op reads x1 (lets a deferred split-K reduction skip materialising it)."""
         C = x1.C + (x2.C if x2 is not None else 0)
+        # (r05) a deferred split-K reduction moves the READ of the producing GEMM's residual into THIS launch -- but the residual's
+        # owner may have released it at plan time right after emitting the GEMM (unet_plan: the transformer block's input is freed as
+        # soon as the block's last GEMM is emitted), and the operand buffers allocated below come out of the same size class: the
+        # GroupNorm would then write its output planes over rows other workgroups have not read yet (found by tools/verify_deferred.py
+        # on BASELINE config 3 at batch 32: latent error 0.1).  Hold such a buffer back until this op is emitted.
+        held = None
+        if SK_DEFER and self.nsplit == 2 and self.prog.ops and self.prog.ops[-1][0] == _lib.OP_KINDS["FRIDO_OP_GEMM"]:
+            prev = self.prog.ops[-1][1]
+            if prev.splitk > 1 and prev.residual and prev.out_f32 == x1.ptr:
+                held = self.pool.hold(prev.residual)
         a = self.op(B * HW, C)
         xb = getattr(x1, "bf16", False)
         alias_raw = want_raw and xb and x2 is None          # a bf16 activation already IS its own operand
@@ -518,6 +528,8 @@ class Builder:
             self.prog.emit("FRIDO_OP_GN_APPLY", nsplit_px=S, partials=part.data_ptr(), **kw)
         if part is not None:
             self.pool.release(part)
+        if held is not None:
+            self.pool.release(held)
         if alias_raw:
             raw = Alias(x1)
         if out_f32:

@@ -4,6 +4,7 @@
 // Reductions use wave64 shuffles; cross-wave / cross-workgroup combination is in a fixed order
 // (no float atomics) so results are bit-reproducible run to run.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -488,77 +489,112 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const FridoGnApply d, int 
 // x1 from the raw split-K partial sums of its producer (FridoGnApply.sk_*): splitk_reduce8_kernel's arithmetic, expression for
 // expression (slices added in ascending order from 0.f, then alpha * sum + (bias + rowvec), then the residual), so the value is
 // bit-identical to what the reduce launch would have stored; INFL slices' loads in flight per lane (the 1024-thread form has 128 registers: 4)
-template <int INFL>
-__device__ __forceinline__ void sk_finish8(const FridoGnApply& d, int64_t m, int c, int vstep, float (&v)[8]) {
+template <int INFL, int VW>
+__device__ __forceinline__ void sk_finish(const FridoGnApply& d, int64_t m, int c, int vstep, float (&v)[VW]) {
+    constexpr int Q = VW / 4;      // float4 pieces per vector
     const int64_t plane = (int64_t)d.B * d.HW * d.C1;
     const float* w = d.sk_ws + m * d.C1 + c;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int e = 0; e < VW; ++e) v[e] = 0.f;
     for (int z0 = 0; z0 < d.sk_n; z0 += INFL) {
-        float4 a[INFL], b[INFL];
+        float4 a[INFL][Q];
 #pragma unroll
         for (int u = 0; u < INFL; ++u)
             if (z0 + u < d.sk_n) {
-                a[u] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane);
-                b[u] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane + 4);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) a[u][q] = *reinterpret_cast<const float4*>(w + (z0 + u) * plane + 4 * q);
             }
 #pragma unroll
         for (int u = 0; u < INFL; ++u)
             if (z0 + u < d.sk_n) {
-                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { v[4 * q] += a[u][q].x; v[4 * q + 1] += a[u][q].y; v[4 * q + 2] += a[u][q].z; v[4 * q + 3] += a[u][q].w; }
             }
     }
-    float add[8];
+    float add[VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) add[e] = 0.f;
+    for (int e = 0; e < VW; ++e) add[e] = 0.f;
     if (d.sk_bias) {
-        const float4 a = *reinterpret_cast<const float4*>(d.sk_bias + c), b = *reinterpret_cast<const float4*>(d.sk_bias + c + 4);
-        add[0] += a.x; add[1] += a.y; add[2] += a.z; add[3] += a.w; add[4] += b.x; add[5] += b.y; add[6] += b.z; add[7] += b.w;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(d.sk_bias + c + 4 * q);
+            add[4 * q] += a.x; add[4 * q + 1] += a.y; add[4 * q + 2] += a.z; add[4 * q + 3] += a.w;
+        }
     }
     if (d.sk_rowvec) {
         const float* rp = d.sk_rowvec + (int64_t)((int)m / d.sk_rows_per_vec + vstep) * d.sk_ldv + c;
-        const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
-        add[0] += a.x; add[1] += a.y; add[2] += a.z; add[3] += a.w; add[4] += b.x; add[5] += b.y; add[6] += b.z; add[7] += b.w;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(rp + 4 * q);
+            add[4 * q] += a.x; add[4 * q + 1] += a.y; add[4 * q + 2] += a.z; add[4 * q + 3] += a.w;
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * d.sk_alpha + add[e];
+    for (int e = 0; e < VW; ++e) v[e] = v[e] * d.sk_alpha + add[e];
     if (d.sk_residual) {
         const float* rp = d.sk_residual + m * d.sk_ldr + c;
-        const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(rp + 4 * q);
+            v[4 * q] += a.x; v[4 * q + 1] += a.y; v[4 * q + 2] += a.z; v[4 * q + 3] += a.w;
+        }
     }
     if (d.sk_out) {
         float* o = d.sk_out + m * d.C1 + c;
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 }
 
-template <int NT, int GNF32_MAXV>
+// VW = channels per lane: 8 (two 16-byte loads, one 16-byte store per plane) or -- r05 -- 4: a chunk is then any run of whole groups
+// that is a multiple of FOUR channels, i.e. TWO groups instead of four at C = 576 / 960, so the launches of the 16 x 16 and 8 x 8
+// planes put 256 workgroups on the chip instead of 128 (a CU streams ~10 - 25 B / cycle: with half the CUs idle the slices' loads,
+// not the arithmetic, set the launch time).
+template <int VW>
+__device__ __forceinline__ void store_planes(frido_bf16* op, int64_t lo_off, int nsplit, const float (&y)[VW]) {
+    uint32_t h[VW], l[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) split_op(y[e], nsplit, h[e], l[e]);
+    if constexpr (VW == 8) {
+        *reinterpret_cast<u32x4*>(op) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        if (nsplit == 2)
+            *reinterpret_cast<u32x4*>(op + lo_off) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    } else {
+        *reinterpret_cast<uint2*>(op) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        if (nsplit == 2) *reinterpret_cast<uint2*>(op + lo_off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+template <int VW>
+__device__ __forceinline__ bool sat_vec(const float (&y)[VW]) {
+    if constexpr (VW == 8) return op_sat8(y);
+    else return op_sat4(y);
+}
+
+template <int NT, int GNF32_MAXV, int VW>
 __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, int Cc) {
+    constexpr int Q = VW / 4;
     __shared__ double s_red[NT / 64][8];
     __shared__ float s_mean[4], s_rstd[4];
     const int C = d.C1 + d.C2, cpg = C / d.groups;
     const int t = threadIdx.x, b = blockIdx.y, lane = t & 63, wave = t >> 6;
     const int c0 = blockIdx.x * Cc;
-    const int vpp = Cc >> 3;                              // 8-channel vectors per pixel
+    const int vpp = Cc / VW;                              // VW-channel vectors per pixel
     const int ppi = NT / vpp;                             // pixels per sweep
     const int cv = t % vpp, pl = t / vpp;
     const bool live = pl < ppi;
-    const int c = c0 + cv * 8;
+    const int c = c0 + cv * VW;
     const float* src;
     int ldx;
     if (c < d.C1) { src = d.x1 + c; ldx = d.C1; }
     else { src = d.x2 + (c - d.C1); ldx = d.C2; }
     src += (int64_t)b * d.HW * ldx;
-    int gi[8];
+    int gi[VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) gi[e] = (cv * 8 + e) / cpg;
-    float xv[GNF32_MAXV][8];
-    float cs[8], cq[8];
+    for (int e = 0; e < VW; ++e) gi[e] = (cv * VW + e) / cpg;
+    float xv[GNF32_MAXV][VW];
+    float cs[VW], cq[VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+    for (int e = 0; e < VW; ++e) cs[e] = cq[e] = 0.f;
     const bool from_sk = d.sk_ws != nullptr && c < d.C1;       // this lane's channels come from a split-K producer's partial sums
     int sk_vstep = 0;
     if (from_sk && d.sk_rowvec && d.sk_rowvec_step) sk_vstep = *d.sk_rowvec_step;
@@ -567,37 +603,40 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
         const int p = pl + k * ppi;
         if (from_sk) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[k][e] = 0.f;
-            if (live && p < d.HW) sk_finish8<(NT == 1024 ? 4 : 8)>(d, (int64_t)b * d.HW + p, c, sk_vstep, xv[k]);
+            for (int e = 0; e < VW; ++e) xv[k][e] = 0.f;
+            if (live && p < d.HW) sk_finish<(NT == 1024 ? 4 : 8), VW>(d, (int64_t)b * d.HW + p, c, sk_vstep, xv[k]);
             continue;
         }
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bq = a;
-        if (live && p < d.HW) {
-            a = *reinterpret_cast<const float4*>(src + (int64_t)p * ldx);
-            bq = *reinterpret_cast<const float4*>(src + (int64_t)p * ldx + 4);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && p < d.HW) a = *reinterpret_cast<const float4*>(src + (int64_t)p * ldx + 4 * q);
+            xv[k][4 * q] = a.x; xv[k][4 * q + 1] = a.y; xv[k][4 * q + 2] = a.z; xv[k][4 * q + 3] = a.w;
         }
-        xv[k][0] = a.x; xv[k][1] = a.y; xv[k][2] = a.z; xv[k][3] = a.w; xv[k][4] = bq.x; xv[k][5] = bq.y; xv[k][6] = bq.z; xv[k][7] = bq.w;
     }
 #pragma unroll
     for (int k = 0; k < GNF32_MAXV; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { cs[e] += xv[k][e]; cq[e] = fmaf(xv[k][e], xv[k][e], cq[e]); }
+        for (int e = 0; e < VW; ++e) { cs[e] += xv[k][e]; cq[e] = fmaf(xv[k][e], xv[k][e], cq[e]); }
     // SPADE gamma / beta do not depend on the statistics: fetch them now, under the reduction
-    float4 gv[GNF32_MAXV][2], bv[GNF32_MAXV][2];
+    float4 gv[GNF32_MAXV][Q], bv[GNF32_MAXV][Q];
     if (d.gamma) {
 #pragma unroll
         for (int k = 0; k < GNF32_MAXV; ++k) {
             const int p = pl + k * ppi;
             if (live && p < d.HW) {
                 const int64_t o = ((int64_t)b * d.HW + p) * C + c;
-                gv[k][0] = *reinterpret_cast<const float4*>(d.gamma + o); gv[k][1] = *reinterpret_cast<const float4*>(d.gamma + o + 4);
-                bv[k][0] = *reinterpret_cast<const float4*>(d.beta + o); bv[k][1] = *reinterpret_cast<const float4*>(d.beta + o + 4);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    gv[k][q] = *reinterpret_cast<const float4*>(d.gamma + o + 4 * q);
+                    bv[k][q] = *reinterpret_cast<const float4*>(d.beta + o + 4 * q);
+                }
             }
         }
     }
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < VW; ++e)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (gi[e] == g) { gs[g] += cs[e]; gq[g] += cq[e]; }
@@ -621,9 +660,9 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
     }
     __syncthreads();
     if (!live) return;
-    float sc[8], sh[8];
+    float sc[VW], sh[VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < VW; ++e) {
         const float r = s_rstd[gi[e]] * d.weight[c + e];
         sc[e] = r;
         sh[e] = d.bias[c + e] - s_mean[gi[e]] * r;
@@ -634,33 +673,24 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
         const int p = pl + k * ppi;
         if (p >= d.HW) break;
         const int64_t o = ((int64_t)b * d.HW + p) * C + c;
-        float y[8];
+        float y[VW];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = fmaf(xv[k][e], sc[e], sh[e]);
+        for (int e = 0; e < VW; ++e) y[e] = fmaf(xv[k][e], sc[e], sh[e]);
         if (d.gamma) {
-            const float4 g0 = gv[k][0], g1 = gv[k][1], b0 = bv[k][0], b1 = bv[k][1];
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = fmaf(y[e], 1.f + gg[e], be[e]);
+            for (int q = 0; q < Q; ++q) {
+                const float4 g4 = gv[k][q], b4 = bv[k][q];
+                y[4 * q] = fmaf(y[4 * q], 1.f + g4.x, b4.x); y[4 * q + 1] = fmaf(y[4 * q + 1], 1.f + g4.y, b4.y);
+                y[4 * q + 2] = fmaf(y[4 * q + 2], 1.f + g4.z, b4.z); y[4 * q + 3] = fmaf(y[4 * q + 3], 1.f + g4.w, b4.w);
+            }
         }
         if (d.act == FRIDO_ACT_SILU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+            for (int e = 0; e < VW; ++e) y[e] = silu_f(y[e]);
         }
-        uint32_t h[8], l[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) split_op(y[e], d.nsplit, h[e], l[e]);
-        if (d.nsplit == 2) sat |= op_sat8(y) || (d.raw_op && op_sat8(xv[k]));
-        *reinterpret_cast<u32x4*>(d.out_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-        if (d.nsplit == 2)
-            *reinterpret_cast<u32x4*>(d.out_op + d.out_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-        if (d.raw_op) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) split_op(xv[k][e], d.nsplit, h[e], l[e]);
-            *reinterpret_cast<u32x4*>(d.raw_op + o) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-            if (d.nsplit == 2)
-                *reinterpret_cast<u32x4*>(d.raw_op + d.raw_lo + o) = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-        }
+        if (d.nsplit == 2) sat |= sat_vec<VW>(y) || (d.raw_op && sat_vec<VW>(xv[k]));
+        store_planes<VW>(d.out_op + o, d.out_lo, d.nsplit, y);
+        if (d.raw_op) store_planes<VW>(d.raw_op + o, d.raw_lo, d.nsplit, xv[k]);
     }
     status_raise(sat);
 }
@@ -877,21 +907,13 @@ extern "C" int frido_gn_apply(const FridoGnApply* d, frido_stream_t s) {
     return frido_check_launch("gn_apply");
 }
 
-// Chunk width of the one-launch GroupNorm: the smallest run of whole groups that is a multiple of 8 channels; 0 if the op
-// does not qualify (then the caller uses gn_stats + gn_apply).
-extern "C" int frido_gn_fused_chunk(const FridoGnApply* d, int* nthreads) {
-    if (!d || d->out_f32 || !d->out_op) return 0;
-    const bool bf16_form = d->x_bf16 && (!d->gamma || d->gb_bf16) && d->nsplit == 1;      // bf16 stream -> one bf16 plane
-    const bool f32_form = !d->x_bf16 && (!d->gamma || !d->gb_bf16);                        // f32 stream -> hi (+ lo) planes
-    if (!bf16_form && !f32_form) return 0;
-    if (((d->C1 | d->C2) & 7) || d->groups <= 0) return 0;
-    const int C = d->C1 + d->C2;
-    if (C % d->groups) return 0;
-    const int cpg = C / d->groups;
+// (Cc, nt) of the f32 / bf16 form for a given vector width; 0 if no chunk of <= 4 whole groups is a multiple of `vw` channels
+static int gn_fused_pick(const FridoGnApply* d, int vw, bool f32_form, int* nthreads) {
+    const int C = d->C1 + d->C2, cpg = C / d->groups;
     int G = 1;
-    while (G <= 4 && (G * cpg) % 8) ++G;
+    while (G <= 4 && (G * cpg) % vw) ++G;
     if (G > 4 || d->groups % G) return 0;
-    const int Cc = G * cpg, vpp = Cc / 8;
+    const int Cc = G * cpg, vpp = Cc / vw;
     for (int nt = 256; nt <= (f32_form ? 1024 : 256); nt *= 2) {
         if (vpp > nt) continue;
         const int ppi = nt / vpp;
@@ -903,6 +925,45 @@ extern "C" int frido_gn_fused_chunk(const FridoGnApply* d, int* nthreads) {
     return 0;
 }
 
+// Chunk width of the one-launch GroupNorm: the smallest run of whole groups that is a multiple of 8 channels -- or (r05, f32 form) of 4
+// channels, when that doubles the workgroups of a launch that would leave CUs idle; 0 if the op does not qualify (then the caller
+// uses gn_stats + gn_apply).  Cc % 8 != 0 tells the launcher that the 4-channel form was chosen.
+extern "C" int frido_gn_fused_chunk(const FridoGnApply* d, int* nthreads) {
+    if (!d || d->out_f32 || !d->out_op) return 0;
+    const bool bf16_form = d->x_bf16 && (!d->gamma || d->gb_bf16) && d->nsplit == 1;      // bf16 stream -> one bf16 plane
+    const bool f32_form = !d->x_bf16 && (!d->gamma || !d->gb_bf16);                        // f32 stream -> hi (+ lo) planes
+    if (!bf16_form && !f32_form) return 0;
+    if (((d->C1 | d->C2) & 7) || d->groups <= 0) return 0;
+    const int C = d->C1 + d->C2;
+    if (C % d->groups) return 0;
+    int nt8 = 0, nt4 = 0;
+    int Cc8 = 0;      // (a lane's vector never straddles the two tensors of a virtual concat: C1 % 8 == 0)
+    {
+        const int cpg = C / d->groups;
+        int G = 1;
+        while (G <= 4 && (G * cpg) % 8) ++G;
+        if (G <= 4 && d->groups % G == 0) {
+            const int Cc = G * cpg, vpp = Cc / 8;
+            for (int nt = 256; nt <= (f32_form ? 1024 : 256); nt *= 2) {
+                if (vpp > nt) continue;
+                const int ppi = nt / vpp;
+                if ((d->HW + ppi - 1) / ppi <= (f32_form ? (nt == 1024 ? 3 : 4) : GNF_MAXV)) { nt8 = nt; Cc8 = Cc; break; }
+            }
+        }
+    }
+    static const bool v4_on = !(getenv("FRIDO_GN_FUSED_V4") && atoi(getenv("FRIDO_GN_FUSED_V4")) == 0);      // A/B switch
+    if (f32_form && v4_on) {
+        const int Cc4 = gn_fused_pick(d, 4, true, &nt4);
+        // the 4-channel form where it at least doubles a grid that does not fill the chip (256 CUs)
+        if (Cc4 > 0 && (Cc4 & 7) && (Cc8 == 0 || ((C / Cc8) * d->B < 256 && Cc4 * 2 <= Cc8))) {
+            if (nthreads) *nthreads = nt4;
+            return Cc4;
+        }
+    }
+    if (Cc8 > 0 && nthreads) *nthreads = nt8;
+    return Cc8;
+}
+
 extern "C" int frido_gn_fused(const FridoGnApply* d, frido_stream_t s) {
     FRIDO_REQUIRE(d && d->x1 && d->out_op && d->weight && d->bias, "null pointer");
     int nt = 0;
@@ -912,15 +973,25 @@ extern "C" int frido_gn_fused(const FridoGnApply* d, frido_stream_t s) {
                                 (!d->sk_rowvec || d->sk_rows_per_vec > 0) && (int64_t)d->B * d->HW < (1ll << 31)),
                   "sk_ws (x1 from split-K partial sums): f32 input, >= 2 slices, C1 % 8 == 0, 4-element aligned strides");
     const int C = d->C1 + d->C2;
+    const int vw = (Cc & 7) ? 4 : 8;
     // (r05) an sk_ws launch takes the 1024-thread form whatever the plain launch would use: every lane then owns ONE vector of ONE
     // pixel and has all its slices' loads in flight at once (the 256-thread form walked 4 vectors x sk_n slices in 4 dependent rounds;
     // measured r04: -2 us per launch).  The statistics' wave-partial order differs from the plain launch's: deferred and undeferred
     // reductions agree to fp32 rounding (<= 1e-6 relative on the normalised output), no longer bit for bit.
-    if (d->sk_ws && !d->x_bf16 && nt < 1024 && Cc / 8 <= 1024) nt = 1024;
-    if (d->x_bf16) hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
-    else if (nt == 256) hipLaunchKernelGGL((gn_fused_f32_kernel<256, 4>), dim3(C / Cc, d->B), dim3(256), 0, (hipStream_t)s, *d, Cc);
-    else if (nt == 512) hipLaunchKernelGGL((gn_fused_f32_kernel<512, 4>), dim3(C / Cc, d->B), dim3(512), 0, (hipStream_t)s, *d, Cc);
-    else hipLaunchKernelGGL((gn_fused_f32_kernel<1024, 3>), dim3(C / Cc, d->B), dim3(1024), 0, (hipStream_t)s, *d, Cc);
+    static const bool sk1024 = !(getenv("FRIDO_GN_FUSED_SK1024") && atoi(getenv("FRIDO_GN_FUSED_SK1024")) == 0);      // A/B switch
+    if (sk1024 && d->sk_ws && !d->x_bf16 && nt < 1024 && Cc / vw <= 1024) nt = 1024;
+    const dim3 grid(C / Cc, d->B);
+    hipStream_t st = (hipStream_t)s;
+    if (d->x_bf16) hipLaunchKernelGGL(gn_fused_kernel<256>, grid, dim3(256), 0, st, *d, Cc);
+    else if (vw == 8) {
+        if (nt == 256) hipLaunchKernelGGL((gn_fused_f32_kernel<256, 4, 8>), grid, dim3(256), 0, st, *d, Cc);
+        else if (nt == 512) hipLaunchKernelGGL((gn_fused_f32_kernel<512, 4, 8>), grid, dim3(512), 0, st, *d, Cc);
+        else hipLaunchKernelGGL((gn_fused_f32_kernel<1024, 3, 8>), grid, dim3(1024), 0, st, *d, Cc);
+    } else {
+        if (nt == 256) hipLaunchKernelGGL((gn_fused_f32_kernel<256, 4, 4>), grid, dim3(256), 0, st, *d, Cc);
+        else if (nt == 512) hipLaunchKernelGGL((gn_fused_f32_kernel<512, 4, 4>), grid, dim3(512), 0, st, *d, Cc);
+        else hipLaunchKernelGGL((gn_fused_f32_kernel<1024, 3, 4>), grid, dim3(1024), 0, st, *d, Cc);
+    }
     return frido_check_launch("gn_fused");
 }
 

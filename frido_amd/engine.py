@@ -121,6 +121,18 @@ class Pool:
     def release(self, buf):
         self.free_bufs.setdefault(buf.numel(), []).append(buf)
 
+    def hold(self, ptr):
+        """Take the FREE buffer that starts at device address `ptr` out of circulation (returns it, or None if no free buffer starts
+        there): an op about to be emitted still reads it although its owner released it at plan time (builder.groupnorm with a
+        deferred split-K reduction: the GEMM's residual is read by the GroupNorm launch).  release() it after the emission."""
+        if not ptr:
+            return None
+        for lst in self.free_bufs.values():
+            for i, t in enumerate(lst):
+                if t.data_ptr() == ptr:
+                    return lst.pop(i)
+        return None
+
 
 class F32:
     """Activation [rows][C] of the residual stream in a pooled buffer: f32, or (bf16 = True) a single bf16 plane that

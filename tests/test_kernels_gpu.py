@@ -527,7 +527,7 @@ def test_attention_flash(nsplit, B, Nq, Nk, d, monkeypatch):
     tol = 5e-5 if nsplit == 2 else 2e-2
     assert _relerr(o.to_f32().cpu().view(B, Nq, d), ref) < tol
     assert _relerr(o2.to_f32().cpu(), ref.reshape(B * Nq, d) + bias + r.to_f32().cpu()) < tol
-    assert hasattr(o2, "ln_copy") == (nsplit == 2 and d in (256, 384))      # the LayerNorm of the stream rows from the same launch
+    assert hasattr(o2, "ln_copy") == (nsplit == 2 and b._flash_ln_ok(d))      # the LayerNorm of the stream rows from the same launch (d = 256, 384; 512 on the d-split form)
     if hasattr(o2, "ln_copy"):
         assert _relerr(o2.ln_copy.to_f32().cpu(), F.layer_norm(o2.to_f32().cpu(), (d,), lw, lb, 1e-5)) < 2e-5
 
@@ -1009,17 +1009,20 @@ def test_gn_conv_fused(case):
         assert _relerr(parts[:, :, 0], blocks.sum(1)) < 1e-5 and _relerr(parts[:, :, 1], (blocks ** 2).sum(1)) < 1e-5
 
 
-@pytest.mark.parametrize("W,C1,C2,Cout_prev,splitk,spade,resid,dead", [(16, 576, 0, 576, 4, False, False, False), (8, 960, 0, 960, 8, True, True, False),
-                                                                       (16, 384, 192, 384, 3, False, True, False), (8, 960, 0, 960, 5, False, False, True)])
-def test_splitk_reduction_deferred_into_groupnorm(W, C1, C2, Cout_prev, splitk, spade, resid, dead):
+@pytest.mark.parametrize("W,C1,C2,Cout_prev,splitk,spade,resid,dead,B", [(16, 576, 0, 576, 4, False, False, False, 16), (8, 960, 0, 960, 8, True, True, False, 16),
+                                                                         (16, 384, 192, 384, 3, False, True, False, 16), (8, 960, 0, 960, 5, False, False, True, 16),
+                                                                         # r05: the shapes of BASELINE config 3 at its batch (CFG: 64 rows): 8 x 8 x 576 and 4 x 4 x 960
+                                                                         (8, 576, 0, 576, 3, False, True, False, 64), (4, 960, 0, 960, 6, True, True, False, 64),
+                                                                         (4, 960, 0, 960, 6, False, False, True, 2)])
+def test_splitk_reduction_deferred_into_groupnorm(W, C1, C2, Cout_prev, splitk, spade, resid, dead, B):
     """r04 (FridoGemm.sk_mode 2 + FridoGnApply.sk_*): a split-K conv whose output goes straight into a one-launch GroupNorm leaves its
     reduction + epilogue (bias, timestep vector, residual) to that launch.  Everything the pair produces -- the conv output, the
     normalised operand, the raw operand copy -- must equal the conv -> splitk_reduce -> GroupNorm chain BIT FOR BIT, and fp32 torch."""
     import frido_amd.builder as bld
     from frido_amd import tune, _lib
     from frido_amd.builder import ACT_SILU
-    B, H, Cin = 16, W, 64
-    HW, M, C = H * W, 16 * W * W, C1 + C2
+    H, Cin = W, 64
+    HW, M, C = H * W, B * W * W, C1 + C2
     xin = _t("sd:x", B, Cin, H, W)
     wc, bc = _t("sd:wc", C1, Cin, 3, 3) / np.sqrt(9 * Cin), _t("sd:bc", C1)
     w, bi = 1 + 0.1 * _t("sd:gw", C), 0.1 * _t("sd:gb", C)
@@ -1058,6 +1061,10 @@ def test_splitk_reduction_deferred_into_groupnorm(W, C1, C2, Cout_prev, splitk, 
         st.ws = tune.workspace_for(st, b.device)
         b.prog._packed = None
         f1.view().fill_(float("nan"))              # whoever finishes the reduction must write every element
+        r_ptr = r.ptr if r is not None else None
+        if r is not None:
+            r.free()                               # (r05) like unet_plan: the residual's owner releases it right after emitting the GEMM -- a deferred
+            #                                        reduction reads it from the GroupNorm launch, whose operand buffers must not be carved out of it
         bld.SK_DEFER = defer
         try:
             a, raw = b.groupnorm(f1, f2, B, HW, "n", 1e-5, gamma=g, beta=be, act=ACT_SILU, want_raw=True, x1_dead=dead)
@@ -1065,6 +1072,8 @@ def test_splitk_reduction_deferred_into_groupnorm(W, C1, C2, Cout_prev, splitk, 
             bld.SK_DEFER = True
         kinds = [k for k, _ in b.prog.ops]
         assert kinds[-1] == _lib.OP_KINDS["FRIDO_OP_GN_FUSED"]
+        if defer and r_ptr is not None:
+            assert a.ptr != r_ptr and raw.ptr != r_ptr, "the deferred reduction's residual was handed out as an output buffer of the same launch"
         assert st.sk_mode == (2 if defer else 0) and bool(b.prog.ops[-1][1].sk_ws) == defer
         _run(b)
         outs[defer] = (f1.view().clone(), a.to_f32().clone(), raw.to_f32().clone())

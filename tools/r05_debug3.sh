@@ -1,0 +1,9 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+export FRIDO_TUNE_CACHE=/tmp/t_v.json FRIDO_TUNE_ON_MISS=tune FRIDO_TUNE_CACHE_READONLY=0
+python tools/verify_deferred.py config3 32 2>&1 | grep -v amdgpu.ids > $OUT/r05_verify_deferred_c3_b32.txt
+grep -E "MISMATCH|checked|WORST|Error|error" $OUT/r05_verify_deferred_c3_b32.txt | head -30
+python tools/verify_deferred.py config3 1 2>&1 | grep -v amdgpu.ids > $OUT/r05_verify_deferred_c3_b1.txt
+grep -E "MISMATCH|checked|WORST|Error|error" $OUT/r05_verify_deferred_c3_b1.txt | head -30
+T="tests/test_model_gpu.py::test_other_configs_at_their_per_gpu_batch"
+echo "== tuned, FRIDO_GN_FUSED_SK1024=0"; FRIDO_GN_FUSED_SK1024=0 FRIDO_TUNE_CACHE=/tmp/t_9.json timeout 900 python -m pytest "$T" -q -x -s -k config3 2>&1 | grep -E "rows .* vs B = 1|passed|failed" | tail -2
