@@ -445,7 +445,13 @@ struct FDGeo {
     // K DOUBLE-buffered where it fits (d = 384: 2 x 48 + 48 + 16 = exactly 160 KiB; d = 256): K_{j+1} then streams in during ALL of tile j
     // instead of having to land inside the 36-MFMA P V phase (measured: the single-buffered form spends ~1.3 us per phase waiting for
     // the other buffer's 48 KiB -- both phases are shorter than one DMA round trip); only V^T_j's load stays exposed to phase 1
-    static constexpr bool KDB = 2 * KBUF + VBUF + XCH <= 163840;
+#ifndef FLASH_DS_KDB
+#define FLASH_DS_KDB 1
+#endif
+#ifndef FLASH_DS_COUNTED
+#define FLASH_DS_COUNTED 1
+#endif
+    static constexpr bool KDB = FLASH_DS_KDB && 2 * KBUF + VBUF + XCH <= 163840;
     static constexpr int KSTRIDE = KDB ? KBUF : 0;       // byte distance between the two K buffers
     static constexpr int V0 = (KDB ? 2 : 1) * KBUF;      // V^T tile offset
     static constexpr int X0 = V0 + VBUF;                 // exchange buffer offset
@@ -581,13 +587,18 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // park the partial scores for the partner wave
+        // park the partial scores for the partner wave.  The stores are inline asm (a C++ LDS store would be fenced with vmcnt(0) behind the
+        // DMA just issued), so the compiler's hazard recogniser does NOT see that they read registers the last MFMAs are still writing:
+        // the matrix pipe has no interlock towards an LDS / VMEM read of its destination, and without the wait states below the store of
+        // s1 could pick up the accumulator BEFORE its last product term landed -- a timing-dependent error of one term of the scores
+        // (found as run-to-run differences of 1e-5 when a second process shared the GPU; 2 x 16 wait states cover the 8-pass MFMA's 18).
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0), "+v"(s1));
         asm volatile("ds_write_b128 %0, %1" ::"v"(x_mine), "v"(s0) : "memory");
         asm volatile("ds_write_b128 %0, %1 offset:16" ::"v"(x_mine), "v"(s1) : "memory");
         // ================= phase 2 head: V^T_j and the partner's partials visible =================
         if constexpr (G::KDB) {
             // V^T_j's pieces were issued BEFORE K_{j+1}'s: loads retire in order, so the younger K pieces may stay in flight
-            if (j + 1 < ntiles) wait_vmcnt<NS * ((G::KP + NW - 1) / NW)>();
+            if (FLASH_DS_COUNTED && j + 1 < ntiles) wait_vmcnt<NS * ((G::KP + NW - 1) / NW)>();
             else wait_vmcnt<0>();
         } else {
             wait_vmcnt<0>();

@@ -325,7 +325,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
         //      while the MFMAs of k-step t issue from the first: with one workgroup of 8 waves per CU (or two of 4) the waves
         //      of a SIMD run in lockstep between barriers, so in the plain loop (below, kept for bf16x3 where the second set
         //      does not fit) the matrix pipe idled through every read phase -- 256 x 128 tile: 1100 cycles per k-tile for
-        //      512 cycles of MFMA work.  Measured per tile (tools/_gb_pipe.sh): BK = 64 tiles -8...-12 % per launch; BK = 32 tiles
+        //      512 cycles of MFMA work.  Measured per tile (tools/gemm_sweep.sh -n 1 -t <all tiles> [-v "SPLITK ..."] <shapes>): BK = 64 tiles -8...-12 % per launch; BK = 32 tiles
         //      +-0 (128 x 128, 256 x 128) or spilling (128 x 192, 256 x 256), so they keep the plain loop.  Ring protocol: a stage is free as soon as every wave holds its fragments in
         //      registers, i.e. at the barrier that publishes the NEXT stage, so all D slots carry loads (one more in flight).
         auto wait_younger = [&](int younger) {                  // stages issued after the one waited for (loads retire in order)
