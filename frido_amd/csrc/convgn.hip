@@ -101,7 +101,10 @@ __device__ __forceinline__ void cg_convert(const CgUnit& u, const float (&sc)[8]
     uint32_t h[8], l[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) split_op(y[e], 2, h[e], l[e]);
-    sat |= op_sat8(y);       // (status word, common.h: 4 v_max3 + 1 compare per 8 values, the flag lives in an SGPR pair)
+    // status word (common.h): 4 v_max3 + 1 compare per 8 values, the flag lives in an SGPR pair.  Only values that are actually STAGED count:
+    // a halo / unused slot converts whatever a stand-in pixel holds and then writes zeros (tools/find_saturation.py: those lanes raised the
+    // bit in 5 - 10 of 400 steps of the benchmark, the real pixels in none)
+    sat |= !zero && op_sat8(y);
     hi = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
     lo = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
     if (zero) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }

@@ -318,6 +318,15 @@ std::vector<frido_status_accessor>& status_words() {
 }  // namespace
 void frido_register_status_word(frido_status_accessor fn) { status_words().push_back(fn); }
 
+// diagnostic: the word of ONE translation unit (registration = link order: igemm, convgn, norm, misc, attn, flash, runtime); -1 past the end
+extern "C" int frido_status_word_of(int32_t idx, uint32_t* word) {
+    if (idx < 0 || idx >= (int)status_words().size() || !word) return -1;
+    unsigned w = 0;
+    if (status_words()[idx](&w, 0) != FRIDO_OK) return FRIDO_EHIP;
+    *word = w;
+    return FRIDO_OK;
+}
+
 extern "C" int frido_status_flags(uint32_t* flags, int32_t clear) {
     if (!flags) {
         frido_set_error("frido_status_flags: null pointer");

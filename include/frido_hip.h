@@ -471,6 +471,9 @@ const char* frido_last_error(void);
 #define FRIDO_STATUS_SATURATED 1u
 #define FRIDO_STATUS_NONFINITE 2u
 int frido_status_flags(uint32_t* flags, int32_t clear);
+/* diagnostic: the status word of ONE source file of the library (index = link order: igemm, convgn, norm, misc, attn, flash, runtime);
+ * returns -1 past the last one.  tools/find_saturation.py uses it to name the kernel family that raised a bit. */
+int frido_status_word_of(int32_t idx, uint32_t* word);
 int frido_device_info(int32_t* cu_count, int32_t* gcn_arch_is_gfx950, int64_t* hbm_bytes);
 
 #ifdef __cplusplus
