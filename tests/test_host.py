@@ -321,3 +321,44 @@ def test_diffusion_wrapper_routes_every_conditioning_key_like_the_reference():
         u(x, t, context=c2[0], y=torch.tensor([1, 2]), stage=0)
     with pytest.raises(NotImplementedError, match="without a context"):
         u(x, t, stage=0)
+
+
+def test_plane_format_selection_and_pool_hold_host_logic():
+    """r05 host logic without a GPU: the precision keyword -> (nsplit, plane format) mapping, the thread-local library routing of
+    _lib.use_planes (nesting restores, unknown formats are rejected, both builds export every declared symbol), and Pool.hold -- the fix
+    of the deferred-reduction aliasing bug: a released buffer that an op about to be emitted still reads is taken out of circulation."""
+    import threading
+    from frido_amd import _lib, config
+    from frido_amd.engine import Pool
+    assert (config.nsplit("bf16x3"), config.planes("bf16x3")) == (2, "f16")
+    assert (config.nsplit("bf16x3_bf16"), config.planes("bf16x3_bf16")) == (2, "bf16")
+    assert (config.nsplit("bf16"), config.planes("bf16")) == (1, "f16")
+    with pytest.raises(ValueError):
+        config.nsplit("fp64")
+    assert _lib.active_planes() == "f16"
+    with _lib.use_planes("bf16"):
+        assert _lib.active_planes() == "bf16"
+        with _lib.use_planes("f16"):
+            assert _lib.active_planes() == "f16"
+        assert _lib.active_planes() == "bf16"
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(_lib.active_planes()))      # another thread keeps the default
+        th.start(); th.join()
+        assert seen == ["f16"]
+    assert _lib.active_planes() == "f16"
+    with pytest.raises(ValueError):
+        with _lib.use_planes("fp8"):
+            pass
+    for planes, fmt in (("f16", 1), ("bf16", 0)):          # both builds of the same sources: same ABI, different element format
+        L = _lib.lib(planes)
+        assert L.frido_x3_plane_format() == fmt and L.frido_abi_version() == _lib.ABI_VERSION
+        assert not [s for s in _lib.declared_symbols() if not hasattr(L, s)]
+    pool = Pool(torch.device("cpu"))
+    a, b = pool.alloc(1000), pool.alloc(1000)
+    pa = a.data_ptr()
+    pool.release(a)
+    assert pool.hold(b.data_ptr()) is None                  # b is in use, not free: nothing to hold
+    held = pool.hold(pa)
+    assert held is a and pool.alloc(1000) is not a          # while held, the same size class hands out a fresh buffer
+    pool.release(held)
+    assert pool.alloc(1000) is a
