@@ -27,6 +27,11 @@ __device__ __forceinline__ f32x4 mma(const bf16x8 (&a)[2], const bf16x8 (&b)[2],
     return mfma_op<NS>(a[0], b[0], acc);
 }
 
+// float4 slots per wave of the LayerNorm form's lane-private parking lot: the wave's share of the dv / 16 output fragments (at most
+// ceil(ntall / NW)), G fragments = G float4 per lane per pass of its loop.  One slot = 64 lanes x 16 bytes.
+__host__ __device__ constexpr int attn_park_slots(int nw, int g, int ntall) { return ((ntall + nw - 1) / nw + g - 1) / g * g; }
+constexpr int attn_lanes_g(int nw, int nf) { return (nw == 16 || (nw == 4 && nf == 2)) ? 2 : 4; }
+
 // NW waves per workgroup (4 when the grid alone fills the chip, 8 / 16 on the small planes where only more waves per
 // workgroup shorten the serial load -> MFMA chain), NF = compile-time bound on the 16-key score fragments (Nk <= 16 NF).
 template <int NS, int NW, int NF>
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     // output fragments per LDS transpose group.  r04: 2 as well for the four-wave short-key form (<= 32 keys, the cross-attention of the
     // 32 x 32 plane): its static LDS drops from 20 to 12 KB, so with the 25-KB row buffer of the fused LayerNorm FOUR workgroups fit a
     // CU instead of three and the launch's 1024 workgroups are all resident at once
-    constexpr int G = (NW == 16 || (NW == 4 && NF == 2)) ? 2 : 4;
+    constexpr int G = attn_lanes_g(NW, NF);
     // (r05) transpose slabs.  G = 4: rows of 68 floats, the 16-byte read-back (lane -> row lane/4, 16 columns) is conflict-free as it is.
     // G = 2 (32 columns per row, 8 per lane): with 36-float rows the ds_read_b128 lane groups {rows 0,3,5,6} / {1,2,4,7} met on the
     // same banks two ways (PMC r04: 25 % of the kernel's LDS cycles were conflict cycles); rows of 48 floats with the 4-float chunk
@@ -166,10 +171,14 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
     const int orow = lane >> 2, oc = (lane & 3) * CPL;
     bool sat = false;                              // an operand value beyond the fp16 planes' range (common.h status word)
     float ln_s = 0.f, ln_q = 0.f;                  // LayerNorm of the stream rows (ln_op): this lane's share of its row's sum / sum of squares
-    // ... and the values themselves, parked in (dynamic) LDS at [row][dv + 4]: every lane reads back only what it wrote itself, so the
-    // second pass needs no barrier -- and no round trip through the stores it has just issued (re-reading out_act cost ~15 us a launch)
+    // ... and the values themselves, parked in (dynamic) LDS: every lane reads back only what it wrote itself, so the second pass needs
+    // no barrier -- and no round trip through the stores it has just issued (re-reading out_act cost ~15 us a launch).
+    // (r05) the parking lot is LANE-PRIVATE: slot k of this wave holds the k-th float4 of each of its 64 lanes at [k][lane] -- a
+    // ds_write_b128 / ds_read_b128 of consecutive lanes on consecutive 16-byte slots is conflict-free for every lane grouping of the
+    // hardware.  The r03 form [row][dv + 4] had the read-back's lane groups (rows {0, 3, 5, 6}: row stride 388 = 4 mod 64 banks)
+    // meet on the same banks two ways, in both LayerNorm passes (PMC: 23 % of the kernel's LDS cycles after the slab fix).
     extern __shared__ __attribute__((aligned(16))) float s_rows[];
-    const int ldrow = d.dv + 4;
+    float* park = s_rows + ((size_t)wave * attn_park_slots(NW, G, d.dv >> 4) * 64 + lane) * 4;
     for (int tb = t0; tb < t1; tb += G) {
         const int ng = t1 - tb < G ? t1 - tb : G;
         f32x4 acc[G];
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                     keep[i * 4] = v.x; keep[i * 4 + 1] = v.y; keep[i * 4 + 2] = v.z; keep[i * 4 + 3] = v.w;
                     if (d.ln_op) {
                         ln_s += (v.x + v.y) + (v.z + v.w);
-                        *reinterpret_cast<float4*>(s_rows + orow * ldrow + col + i * 4) = v;
+                        *reinterpret_cast<float4*>(park + (((tb - t0) / G) * (CPL / 4) + i) * 256) = v;
                     }
                 }
                 if (d.out_op) {                 // operand copy of the stream values (A2 of the chained FF2 + proj_out GEMM)
@@ -280,10 +289,10 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
         for (int tb = t0; tb < t1; tb += G) {
             const int ng = t1 - tb < G ? t1 - tb : G;
             if (oc >= ng * 16) continue;
-            const float* xq = s_rows + orow * ldrow + tb * 16 + oc;
+            const float* xq = park + ((tb - t0) / G) * (CPL / 4) * 256;
 #pragma unroll
             for (int i = 0; i < CPL / 4; ++i) {
-                const float4 x = *reinterpret_cast<const float4*>(xq + i * 4);
+                const float4 x = *reinterpret_cast<const float4*>(xq + i * 256);
                 const float a0 = x.x - mean, a1 = x.y - mean, a2 = x.z - mean, a3 = x.w - mean;
                 ln_q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
@@ -297,7 +306,6 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
         const float rstd = 1.0f / sqrtf(Q / d.dv + d.ln_eps);
         status_raise(false, wave == 0 && (lane & 3) == 0 && stat_bad(mean, rstd));
         // second pass over the values this lane parked in LDS
-        const float* xr = s_rows + orow * ldrow;
         frido_bf16* dst = d.ln_op + (int64_t)(row0 + orow) * d.ld_ln;
         for (int tb = t0; tb < t1; tb += G) {
             const int ng = t1 - tb < G ? t1 - tb : G;
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
 #pragma unroll
             for (int i = 0; i < CPL / 8; ++i) {
                 const int c = col + i * 8;
-                const float4 x0 = *reinterpret_cast<const float4*>(xr + c), x1 = *reinterpret_cast<const float4*>(xr + c + 4);
+                const float* xr = park + (((tb - t0) / G) * (CPL / 4) + i * 2) * 256;
+                const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 256);
                 const float4 w0 = *reinterpret_cast<const float4*>(d.ln_w + c), w1 = *reinterpret_cast<const float4*>(d.ln_w + c + 4);
                 const float4 b0 = *reinterpret_cast<const float4*>(d.ln_b + c), b1 = *reinterpret_cast<const float4*>(d.ln_b + c + 4);
                 const float y[8] = {(x0.x - mean) * rstd * w0.x + b0.x, (x0.y - mean) * rstd * w0.y + b0.y, (x0.z - mean) * rstd * w0.z + b0.z,
@@ -345,9 +354,10 @@ int launch_attn(const FridoAttnSmall& d, hipStream_t s) {
     const int blocks = d.B * (d.Nq / 16);
     const bool many = blocks >= 512;                    // >= 2 workgroups per CU: the grid hides the latency chain
     const int cs = blocks >= 256 ? 1 : (blocks >= 128 ? 2 : 4);
-    const size_t dyn = d.ln_op ? (size_t)16 * (d.dv + 4) * sizeof(float) : 0;      // the rows parked for their LayerNorm (<= 62 KiB at dv = 960)
+    // the values parked for their LayerNorm (lane-private slots of 1 KiB per wave: <= 64 KiB at dv = 1024 in every form)
 #define ATTN_LAUNCH(NW, NF)                                                                                               \
     do {                                                                                                                  \
+        const size_t dyn = d.ln_op ? (size_t)NW * attn_park_slots(NW, attn_lanes_g(NW, NF), d.dv >> 4) * 1024 : 0;        \
         if (dyn && !attn_lds_optin<NS, NW, NF>()) {                                                                       \
             frido_set_error("attn_small: cannot opt in to %zu bytes of dynamic LDS", dyn);                                \
             return FRIDO_EHIP;                  /* no launch with an under-provisioned row buffer */                      \
