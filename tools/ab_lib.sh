@@ -4,10 +4,10 @@
 #   tools/ab_lib.sh frido_amd/libfrido_hip_old.so frido_amd/libfrido_hip.so
 A=${1:?old lib}; B=${2:?new lib}
 export FRIDO_TUNE_TAG=ab FRIDO_TUNE_CACHE=/tmp/tune_ab.json
-FRIDO_LIB=$PWD/$A python bench.py --retune --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
+FRIDO_LIB=$PWD/$A python bench.py --retune --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode --no-other-configs > /dev/null 2>&1
 for i in 1 2 3; do
   for L in $A $B; do
-    FRIDO_LIB=$PWD/$L python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode 2>&1 | grep -v amdgpu.ids | tail -1 |
+    FRIDO_LIB=$PWD/$L python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --no-other-configs 2>&1 | grep -v amdgpu.ids | tail -1 |
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$L', d['value'], 'images/s', d['ms_per_step'], 'ms/batch')"
   done
 done
