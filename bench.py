@@ -18,7 +18,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))

@@ -6,9 +6,7 @@ Nothing here computes on the CPU and nothing falls back to torch ops: every tens
 model output is produced by a kernel of libfrido_hip.so.
 """
 import ctypes as C
-import math
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -210,7 +210,6 @@ def test_sampling_script_import_surface():
 def test_caller_surface_of_frido_diffusion():
     """get_img_ids (frido.py:818), q_sample (frido.py:302-320), the CLIP cond-stage target of the t2i YAML."""
     from frido_amd.models import instantiate_from_config
-    from frido_amd import schedules as sch
     cfg = frido_cfg(UNET_SMALL, VQ_SMALL, BERT_SMALL)
     cfg["cond_stage_config"] = dict(target="frido.modules.encoders.modules.FrozenCLIPTextEmbedder")
     cfg["cond_stage_trainable"], cfg["cond_stage_key"] = False, "caption"
