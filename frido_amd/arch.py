@@ -36,6 +36,7 @@ class UNetArch:
     output_blocks: List[List[Blk]] = field(default_factory=list)
     skip_channels: List[int] = field(default_factory=list)   # channels pushed on the skip stack
     image_size: int = 64
+    transformer_depth: int = 1     # BasicTransformerBlocks per SpatialTransformer (attention.py:274-277)
 
 
 def unet_arch(cfg) -> UNetArch:
@@ -48,12 +49,13 @@ def unet_arch(cfg) -> UNetArch:
         raise NotImplementedError("only the SpatialTransformer denoiser (every shipped Frido config) is built")
     if cfg.get("resblock_updown", False) or cfg.get("use_scale_shift_norm", False):
         raise NotImplementedError("resblock_updown / use_scale_shift_norm are not used by any Frido config")
-    if cfg.get("transformer_depth", 1) != 1:
-        raise NotImplementedError("transformer_depth != 1")
+    depth = int(cfg.get("transformer_depth", 1))
+    if depth < 1:
+        raise ValueError("transformer_depth must be >= 1")
     a = UNetArch(model_channels=mc, time_embed_dim=4 * mc, context_dim=cfg.get("context_dim"),
                  num_stage=cfg.get("num_stage", 1), splits=list(cfg.get("split_embed_dim_list", [])),
                  use_spade=cfg.get("use_SPADE_norm", False), use_split_head=cfg.get("use_split_head", False),
-                 in_channels=cfg["in_channels"], image_size=cfg.get("image_size", 64))
+                 in_channels=cfg["in_channels"], image_size=cfg.get("image_size", 64), transformer_depth=depth)
     # pyunet.py:600-609: with the split head input_blocks starts empty, otherwise block 0 is the conv
     idx = 0 if a.use_split_head else 1
     chans = [mc]

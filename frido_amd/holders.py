@@ -116,11 +116,11 @@ class TBlockP(nn.Module):     # attention.py:197-205
 
 
 class SpatialTransformerP(nn.Module):   # attention.py:250-280
-    def __init__(self, c, cond_c, ctx, spade):
+    def __init__(self, c, cond_c, ctx, spade, depth=1):
         super().__init__()
         self.norm = _norm(c, cond_c, spade)
         self.proj_in = Conv(c, c, 1)
-        self.transformer_blocks = nn.ModuleList([TBlockP(c, ctx)])
+        self.transformer_blocks = nn.ModuleList([TBlockP(c, ctx) for _ in range(depth)])
         self.proj_out = Conv(c, c, 1)
 
 
@@ -140,7 +140,7 @@ def _make(b, a):
     if b.kind == "res":
         return ResBlockP(b.cin, b.cout, a.time_embed_dim, a.model_channels, a.use_spade)
     if b.kind == "st":
-        return SpatialTransformerP(b.cin, a.model_channels, a.context_dim, a.use_spade)
+        return SpatialTransformerP(b.cin, a.model_channels, a.context_dim, a.use_spade, a.transformer_depth)
     if b.kind == "down":
         return DownP(b.cin)
     if b.kind == "up":

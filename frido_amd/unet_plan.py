@@ -129,17 +129,18 @@ class UNetStagePlan:
             for blk in grp:
                 if blk.kind != "st":
                     continue
-                t = f"{blk.prefix}.transformer_blocks.0.attn2"
-                C = blk.cin
-                k = b.persistent_op(self.Bx * self.nctx, C, zero=False)
-                wkq, _ = b.folded_qk_weight(t + ".to_q", t + ".to_k", "k")
-                b.linear(ctx_op, None, wop=wkq, bias=False, out=("op", k))
-                wvo, bvo = b.folded_vo_weight(t + ".to_v", t + ".to_out.0")
-                vT = b.v_transposed(ctx_op, a.context_dim, wvo, self.Bx, self.nctx, C)
-                if X3_CROSSKV_HI and b.nsplit == 2:
-                    for o_ in (k, vT):      # zero the residual planes: the cache then carries 8 mantissa bits
-                        prog.emit("FRIDO_OP_FILL", dst=o_.ptr + 2 * o_.lo, n=o_.lo // 2, value=0)
-                self.kv[blk.prefix] = (k, vT, bvo)
+                for dpt in range(a.transformer_depth):
+                    t = f"{blk.prefix}.transformer_blocks.{dpt}.attn2"
+                    C = blk.cin
+                    k = b.persistent_op(self.Bx * self.nctx, C, zero=False)
+                    wkq, _ = b.folded_qk_weight(t + ".to_q", t + ".to_k", "k")
+                    b.linear(ctx_op, None, wop=wkq, bias=False, out=("op", k))
+                    wvo, bvo = b.folded_vo_weight(t + ".to_v", t + ".to_out.0")
+                    vT = b.v_transposed(ctx_op, a.context_dim, wvo, self.Bx, self.nctx, C)
+                    if X3_CROSSKV_HI and b.nsplit == 2:
+                        for o_ in (k, vT):      # zero the residual planes: the cache then carries 8 mantissa bits
+                            prog.emit("FRIDO_OP_FILL", dst=o_.ptr + 2 * o_.lo, n=o_.lo // 2, value=0)
+                    self.kv[(blk.prefix, dpt)] = (k, vT, bvo)
         ctx_op.free()
         # ---- SPADE conditioning (spade_norm.py:44-60), timestep-invariant within a stage ----
         if self.spade_on:
@@ -262,10 +263,21 @@ class UNetStagePlan:
         """attention.py:289-326 with BasicTransformerBlock._forward (222-227), single head d = C."""
         b, HW, C, Bx = self.b, h * w, blk.cin, self.Bx
         pre = blk.prefix
-        t = pre + ".transformer_blocks.0"
         a0, _ = self._norm(x, None, HW, pre + ".norm", 1e-6, ACT_NONE)
         hcur = b.linear(a0, pre + ".proj_in")
         a0.free()
+        depth = self.a.transformer_depth
+        for dpt in range(depth):        # attention.py:274-277,321-322 (every shipped config: depth 1)
+            hcur = self._transformer_block(pre, dpt, hcur, x if dpt == depth - 1 else None, HW, C)     # (frees its input stream)
+        return hcur
+
+    def _transformer_block(self, pre, dpt, hcur, x, HW, C):
+        """BasicTransformerBlock._forward (attention.py:222-227).  `x` is the SpatialTransformer's input for the LAST block
+        (its feed-forward is then chained with proj_out + x into one GEMM), None for the inner blocks of a deeper transformer,
+        which return the token stream itself."""
+        b, Bx = self.b, self.Bx
+        last = x is not None
+        t = f"{pre}.transformer_blocks.{dpt}"
         # --- self-attention
         n1 = b.layernorm(hcur, t + ".norm1")
         # scores: q' = n1 (W_q^T W_k) against the raw rows of n1 (the key projection is folded into the query side)
@@ -291,8 +303,8 @@ class UNetStagePlan:
         n2 = getattr(h2, "ln_copy", None)       # (r03) the attention kernel's epilogue may have produced it
         if n2 is None:
             n2 = b.layernorm(h2, t + ".norm2")
-        kc, vTc, bvo2 = self.kv[pre]            # kc = ctx (W_q^T W_k)^T: the query projection is folded into the cached keys
-        chain = CHAIN_FF and C % 64 == 0       # proj_out(h3 + ff2(gg)) + x in ONE GEMM (needs h3 as an operand along K)
+        kc, vTc, bvo2 = self.kv[(pre, dpt)]     # kc = ctx (W_q^T W_k)^T: the query projection is folded into the cached keys
+        chain = last and CHAIN_FF and C % 64 == 0       # proj_out(h3 + ff2(gg)) + x in ONE GEMM (needs h3 as an operand along K)
         # (r05) with FF2 + proj_out chained, h3 is read only as an operand (A2 of that GEMM) and through norm3: where the kernel
         # produces both copies itself the f32 rows are not stored at all
         h3 = b.attention(n2, C, kc, C, vTc, Bx, HW, self.nctx, C, bias_ptr=bvo2, residual=h2, stream=True, also_op=chain,
@@ -305,6 +317,11 @@ class UNetStagePlan:
             n3 = b.layernorm(h3, t + ".norm3")
         gg = b.linear_geglu(n3, t + ".ff.net.0.proj")
         n3.free()
+        if not last:
+            out = b.linear(gg, t + ".ff.net.2", residual=h3)     # the next block's token stream
+            gg.free()
+            h3.free()
+            return out
         h3op = h3 if b.stream_bf16 else getattr(h3, "op_copy", None)     # bf16 stream: the activation is its own operand
         if chain and h3op is not None:
             # ff2 and proj_out are both linear: [gg | h3] . [W_p W_f | W_p]^T + (W_p b_f + b_p) + x (weights folded in float64);

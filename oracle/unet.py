@@ -80,30 +80,31 @@ def cross_attention(p, pre, x, context):
     return F.linear(out, p(pre + ".to_out.0.weight"), p(pre + ".to_out.0.bias"))
 
 
-def spatial_transformer(p, b, x, context, cond):
+def spatial_transformer(p, b, x, context, cond, depth=1):
     """attention.py:289-326 + BasicTransformerBlock._forward 222-227 + GEGLU 37-44."""
     pre = b.prefix
     B, C, H, W = x.shape
     h = _norm(p, pre + ".norm", x, cond, 1e-6)
     h = _conv(p, pre + ".proj_in", h, padding=0)
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
-    t = pre + ".transformer_blocks.0"
-    ln = lambda n, z: F.layer_norm(z, (C,), p(f"{t}.{n}.weight"), p(f"{t}.{n}.bias"), 1e-5)
-    h = cross_attention(p, t + ".attn1", ln("norm1", h), None) + h
-    h = cross_attention(p, t + ".attn2", ln("norm2", h), context) + h
-    g = F.linear(ln("norm3", h), p(t + ".ff.net.0.proj.weight"), p(t + ".ff.net.0.proj.bias"))
-    a, gate = g.chunk(2, dim=-1)
-    h = F.linear(a * F.gelu(gate), p(t + ".ff.net.2.weight"), p(t + ".ff.net.2.bias")) + h
+    for d in range(depth):      # attention.py:274-277,321-322: `depth` BasicTransformerBlocks in sequence
+        t = f"{pre}.transformer_blocks.{d}"
+        ln = lambda n, z: F.layer_norm(z, (C,), p(f"{t}.{n}.weight"), p(f"{t}.{n}.bias"), 1e-5)
+        h = cross_attention(p, t + ".attn1", ln("norm1", h), None) + h
+        h = cross_attention(p, t + ".attn2", ln("norm2", h), context) + h
+        g = F.linear(ln("norm3", h), p(t + ".ff.net.0.proj.weight"), p(t + ".ff.net.0.proj.bias"))
+        a, gate = g.chunk(2, dim=-1)
+        h = F.linear(a * F.gelu(gate), p(t + ".ff.net.2.weight"), p(t + ".ff.net.2.bias")) + h
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     return _conv(p, pre + ".proj_out", h, padding=0) + x
 
 
-def _run(p, blocks, h, emb, context, cond):
+def _run(p, blocks, h, emb, context, cond, depth=1):
     for b in blocks:
         if b.kind == "res":
             h = res_block(p, b, h, emb, cond)
         elif b.kind == "st":
-            h = spatial_transformer(p, b, h, context, cond)
+            h = spatial_transformer(p, b, h, context, cond, depth)
         elif b.kind == "down":   # pyunet.py:152-156: conv3x3 stride 2 padding 1
             h = _conv(p, b.prefix + ".op", h, stride=2, padding=1)
         elif b.kind == "up":     # pyunet.py:119-121: nearest x2 then conv3x3
@@ -134,16 +135,16 @@ def unet_forward(sd, cfg, x, t, context, stage, prefix="model.diffusion_model.",
         taps["pre"] = h
     hs = [h]
     for i, blk in enumerate(a.input_blocks):
-        h = _run(p, blk, h, emb, context, cond)
+        h = _run(p, blk, h, emb, context, cond, a.transformer_depth)
         hs.append(h)
         if taps is not None and i == 0:
             taps["ib0"] = h
-    h = _run(p, a.middle, h, emb, context, cond)
+    h = _run(p, a.middle, h, emb, context, cond, a.transformer_depth)
     if taps is not None:
         taps["mid"] = h
     for blk in a.output_blocks:
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run(p, blk, h, emb, context, cond)
+        h = _run(p, blk, h, emb, context, cond, a.transformer_depth)
     if taps is not None:
         taps["ob_last"] = h
     o = f"out.{stage}" if a.use_split_head else "out"

@@ -15,6 +15,9 @@ UNET_SMALL = dict(
     num_res_blocks=1, channel_mult=[1, 2, 3], num_head_channels=32,
     use_spatial_transformer=True, transformer_depth=1, context_dim=64, num_stage=2)
 
+# transformer_depth = 2 (attention.py:274-277: two BasicTransformerBlocks per SpatialTransformer) -- no shipped config uses it; r05 fixture
+UNET_SMALL_D2 = dict(UNET_SMALL, transformer_depth=2)
+
 UNET_SMALL3 = dict(
     use_split_head=True, split_embed_dim_list=[3, 3, 3], use_SPADE_norm=True, image_size=16,
     in_channels=9, out_channels=9, model_channels=32, attention_resolutions=[2],

@@ -33,7 +33,7 @@ H = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(H)
 
 sys.path.insert(0, HERE)
-from golden_cfg import (UNET_SMALL, UNET_FULL, VQ_SMALL, VQ_FULL, UNET_SMALL3, VQ_SMALL3, BERT_SMALL,  # noqa: E402
+from golden_cfg import (UNET_SMALL, UNET_SMALL_D2, UNET_FULL, VQ_SMALL, VQ_FULL, UNET_SMALL3, VQ_SMALL3, BERT_SMALL,  # noqa: E402
                         frido_cfg, BERT_FULL, UNET_F16F8, VQ_F16F8, UNET_512, VQ_512)
 
 
@@ -538,6 +538,7 @@ def gen_shipped_cfgs():
 GENS = {
     "schedules": gen_schedules,
     "unet_small": lambda: gen_unet("unet_small", UNET_SMALL, B=2, nctx=5, hw=16),
+    "unet_small_d2": lambda: gen_unet("unet_small_d2", UNET_SMALL_D2, B=2, nctx=5, hw=16),
     "unet_small3": lambda: gen_unet("unet_small3", UNET_SMALL3, B=1, nctx=7, hw=16),
     "unet_full": lambda: gen_unet("unet_full", UNET_FULL, B=1, nctx=26, hw=64, capture=False),
     "vq_small": lambda: gen_vq("vq_small", VQ_SMALL, B=2),

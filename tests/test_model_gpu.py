@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from helpers import golden, synth_sd, unet_holder, vq_holder  # noqa: E402
-from golden_cfg import (UNET_SMALL, UNET_SMALL3, UNET_FULL, VQ_SMALL, VQ_SMALL3, VQ_FULL, BERT_SMALL, frido_cfg)  # noqa: E402
+from golden_cfg import (UNET_SMALL, UNET_SMALL_D2, UNET_SMALL3, UNET_FULL, VQ_SMALL, VQ_SMALL3, VQ_FULL, BERT_SMALL, frido_cfg)  # noqa: E402
 from frido_amd.synth import fill_module  # noqa: E402
 
 
@@ -32,7 +32,7 @@ def _unet(cfg):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("name,cfg", [("unet_small", UNET_SMALL), ("unet_small3", UNET_SMALL3)])
+@pytest.mark.parametrize("name,cfg", [("unet_small", UNET_SMALL), ("unet_small3", UNET_SMALL3), ("unet_small_d2", UNET_SMALL_D2)])
 def test_unet_forward_matches_reference_golden(name, cfg):
     g = golden(name)
     m = _unet(cfg)

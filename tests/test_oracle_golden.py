@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from helpers import golden, synth_sd, unet_holder, vq_holder
-from golden_cfg import UNET_SMALL, UNET_SMALL3, UNET_FULL, VQ_SMALL, VQ_SMALL3, VQ_FULL
+from golden_cfg import UNET_SMALL, UNET_SMALL_D2, UNET_SMALL3, UNET_FULL, VQ_SMALL, VQ_SMALL3, VQ_FULL
 from oracle import samplers as S
 from oracle.unet import unet_forward, timestep_embedding
 from oracle.vqgan import vq_decode, vq_encode, quantize
@@ -30,7 +30,7 @@ def test_schedules_and_timestep_embedding():
     assert np.array_equal(timestep_embedding(t, 32).numpy(), g["temb_32"])
 
 
-@pytest.mark.parametrize("name,cfg", [("unet_small", UNET_SMALL), ("unet_small3", UNET_SMALL3)])
+@pytest.mark.parametrize("name,cfg", [("unet_small", UNET_SMALL), ("unet_small3", UNET_SMALL3), ("unet_small_d2", UNET_SMALL_D2)])
 def test_unet_oracle_bit_exact(name, cfg):
     g = golden(name)
     root = unet_holder(cfg)
