@@ -266,10 +266,11 @@ class BERTEmbedder(_Versioned, nn.Module):
     """Token ids -> x-transformer encoder embeddings [B, n, n_embed] on the HIP engine."""
 
     def __init__(self, n_embed, n_layer, vocab_size=30522, max_seq_len=77, device="cuda", use_tokenizer=True,
-                 embedding_dropout=0.0, cond_key="", precision=None):
+                 embedding_dropout=0.0, cond_key="", precision=None, vocab_file=None):
         super().__init__()
-        self.use_tknz_fn = use_tokenizer      # strings -> ids needs the HF tokenizer files: resolved lazily, at encode time
+        self.use_tknz_fn = use_tokenizer      # strings -> ids needs the tokenizer's vocabulary: resolved lazily, at encode time
         self.tokenizer = None
+        self.vocab_file = vocab_file          # local bert-base-uncased vocab.txt (else $FRIDO_BERT_VOCAB, else the HF cache)
         self.n_embed, self.n_layer, self.vocab_size, self.max_seq_len = n_embed, n_layer, vocab_size, max_seq_len
         self.cond_key, self.precision = cond_key, precision
         holders.build_bert_params(self, n_embed, n_layer, vocab_size, max_seq_len)
@@ -312,9 +313,15 @@ class BERTEmbedder(_Versioned, nn.Module):
         return self(text)
 
     def _tokenize(self, text):
-        """BERTTokenizer of the reference (encoders/modules.py:57-82): HF `bert-base-uncased`, padded / truncated to max_seq_len.
-        The vocabulary files are not reachable offline, so this only works where `transformers` finds them locally; token-id
-        tensors and finished conditioning tensors never come here."""
+        """BERTTokenizer of the reference (encoders/modules.py:57-82): `bert-base-uncased`, [CLS] .. [SEP] padded / truncated to
+        max_seq_len.  The vocabulary is a download, so it is looked for (1) in a local vocab.txt (`vocab_file=` / $FRIDO_BERT_VOCAB:
+        frido_amd/tokenizers.py WordPieceTokenizer, the published BasicTokenizer + WordPiece algorithm), (2) in the local HF cache
+        through `transformers`; with neither a clear error is raised.  Token-id and conditioning tensors never come here."""
+        if self.tokenizer is None:
+            from .tokenizers import WordPieceTokenizer, local_bert_vocab
+            vf = local_bert_vocab(self.vocab_file)
+            if vf is not None:
+                self.tokenizer = WordPieceTokenizer(vf)
         if self.tokenizer is None:
             try:
                 from transformers import BertTokenizerFast
@@ -324,8 +331,12 @@ class BERTEmbedder(_Versioned, nn.Module):
                 self.tokenizer = tk
             except Exception as e:
                 raise NotImplementedError(
-                    "BERTEmbedder: captions given as strings need the HF 'bert-base-uncased' tokenizer files, which are not "
-                    f"reachable offline ({type(e).__name__}); pass token ids ([B, n] int64) or the conditioning tensor instead") from None
+                    "BERTEmbedder: captions given as strings need the 'bert-base-uncased' vocabulary, which is not reachable "
+                    f"offline ({type(e).__name__}); pass vocab_file= / set FRIDO_BERT_VOCAB to a local vocab.txt, or pass token "
+                    "ids ([B, n] int64) or the conditioning tensor instead") from None
+        from .tokenizers import WordPieceTokenizer
+        if isinstance(self.tokenizer, WordPieceTokenizer):
+            return self.tokenizer(text, max_length=self.max_seq_len)
         enc = self.tokenizer(text, truncation=True, max_length=self.max_seq_len, return_length=True, return_overflowing_tokens=False,
                              padding="max_length", return_tensors="pt")
         return enc["input_ids"]
@@ -337,16 +348,18 @@ class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
     `encode` adds the token axis and repeats it n_repeat times.  The tower runs on the HIP engine (clip_plan.ClipTextPlan);
     its weights live under `self.model` with OpenAI CLIP's state_dict names, so a reference checkpoint's
     `cond_stage_model.model.*` keys load.  `forward` takes token ids ([B, 77] int64, what `clip.tokenize` returns); captions as
-    strings need the CLIP byte-pair vocabulary file, which is part of the un-vendored `clip` package: pass `tokenizer=` (any
-    callable list[str] -> LongTensor [B, 77]) or install `clip`; without either a clear error is raised at encode time.
+    strings need the CLIP byte-pair merge table, which is part of the un-vendored `clip` package: pass `bpe_path=` / set
+    $FRIDO_CLIP_BPE (a local bpe_simple_vocab_16e6.txt.gz: frido_amd/tokenizers.py ClipBPETokenizer), pass `tokenizer=` (any
+    callable list[str] -> LongTensor [B, 77]) or install `clip`; without any of them a clear error is raised at encode time.
     `arch` overrides the (embed_dim, context_length, vocab, width, heads, layers) of `version` (tests use a reduced tower)."""
 
     def __init__(self, version="ViT-L/14", device="cuda", max_length=77, n_repeat=1, normalize=True, arch=None, tokenizer=None,
-                 precision=None):
+                 precision=None, bpe_path=None):
         super().__init__()
         self.version, self.device, self.max_length = version, device, max_length
         self.n_repeat, self.normalize, self.use_tknz_fn = n_repeat, normalize, True
         self.precision, self.tokenizer = precision, tokenizer
+        self.bpe_path = bpe_path              # local CLIP merge table (bpe_simple_vocab_16e6.txt.gz; else $FRIDO_CLIP_BPE)
         if arch is None:
             if version not in holders.CLIP_TEXT_ARCH:
                 raise NotImplementedError(f"FrozenCLIPTextEmbedder: unknown CLIP version '{version}' "
@@ -368,6 +381,11 @@ class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
     def _tokens(self, text):
         if torch.is_tensor(text):
             return text
+        if self.tokenizer is None:
+            from .tokenizers import ClipBPETokenizer, local_clip_bpe
+            bp = local_clip_bpe(self.bpe_path)
+            if bp is not None:      # frido_amd/tokenizers.py: the published byte-level BPE of clip/simple_tokenizer.py over a local file
+                self.tokenizer = ClipBPETokenizer(bp, context_length=self.arch[1])
         if self.tokenizer is not None:
             return self.tokenizer(text)
         try:
@@ -376,7 +394,8 @@ class FrozenCLIPTextEmbedder(_Versioned, nn.Module):
         except ImportError:
             raise NotImplementedError(
                 "FrozenCLIPTextEmbedder: captions given as strings need CLIP's byte-pair vocabulary (`clip.tokenize`); the `clip` "
-                "package is not reachable offline -- pass token ids ([B, 77] int64), a tokenizer= callable, or the finished "
+                "package is not reachable offline -- pass bpe_path= / set FRIDO_CLIP_BPE to a local bpe_simple_vocab_16e6.txt.gz, pass "
+                "token ids ([B, 77] int64), a tokenizer= callable, or the finished "
                 "[B, n_repeat, embed_dim] embedding to the sampler as `conditioning`") from None
 
     planes = property(lambda self: config.planes(self.precision))
