@@ -32,8 +32,14 @@ int frido_convgn_init();
 // Timing ablations of the bf16x3 main loop (tools/build_ablate.sh builds SEPARATE libraries with -DFRIDO_ABLATE=<mask>; the shipped
 // library is built with 0 and contains none of this): 1 = no DMA refills inside the loop, 2 = no fragment reads, 4 = no barriers /
 // vmcnt waits, 8 = no MFMAs.  Results are garbage; only the launch time means anything.
+// 1024 (r05, results stay CORRECT): stagger experiment of DESIGN.md section 7 item 5 -- on the two-per-CU (4-wave) tiles the workgroups
+// with dispatch ids 256 .. 511 (the second resident slot of the first round, if the dispatcher fills one slot per CU first) start
+// FRIDO_STAGGER_US microseconds late, so that from then on one slot's prologue / epilogue runs under the other slot's k-loop.
 #ifndef FRIDO_ABLATE
 #define FRIDO_ABLATE 0
+#endif
+#ifndef FRIDO_STAGGER_US
+#define FRIDO_STAGGER_US 8
 #endif
 #ifndef FRIDO_X3_PIPE_ALL
 #define FRIDO_X3_PIPE_ALL 0      // 1: also run the six-n-tile bf16x3 tiles (128 x 192, 64 x 192) on the virtual-k-step loop
@@ -116,6 +122,13 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    if constexpr ((FRIDO_ABLATE & 1024) && NW == 4) {
+        const int id = ((int)blockIdx.y * (int)gridDim.z + (int)blockIdx.z) * (int)gridDim.x + (int)blockIdx.x;
+        if (id >= 256 && id < 512 && (int)(gridDim.x * gridDim.y * gridDim.z) >= 768) {
+            const uint64_t t0 = wall_clock64();             // 100 MHz
+            while (wall_clock64() - t0 < (uint64_t)(FRIDO_STAGGER_US * 100)) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     // batch index, optionally two-level (outer x inner, e.g. image x head)
     int zo = blockIdx.y, zi = 0;
     if (d.batch_inner > 1) {
