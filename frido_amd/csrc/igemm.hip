@@ -41,6 +41,12 @@ int frido_convgn_init();
 #ifndef FRIDO_STAGGER_US
 #define FRIDO_STAGGER_US 8
 #endif
+// Run-time form of the same (for round 6; -DFRIDO_STAGGER_RT=1 builds only, the shipped library is built with 0 and is bit-identical to
+// the one without this code): the delay in microseconds comes from FridoGemm.flags bits 8..15 (0 = none), the smallest grid it applies
+// to from bits 16..23 in units of 64 workgroups (0 = 768 workgroups).  Python: FRIDO_STAGGER_US / FRIDO_STAGGER_MIN_WG (engine.py).
+#ifndef FRIDO_STAGGER_RT
+#define FRIDO_STAGGER_RT 0
+#endif
 #ifndef FRIDO_X3_PIPE_ALL
 #define FRIDO_X3_PIPE_ALL 0      // 1: also run the six-n-tile bf16x3 tiles (128 x 192, 64 x 192) on the virtual-k-step loop
 #endif
@@ -122,11 +128,13 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    if constexpr ((FRIDO_ABLATE & 1024) && NW == 4) {
+    if constexpr (((FRIDO_ABLATE & 1024) || FRIDO_STAGGER_RT) && NW == 4) {
         const int id = ((int)blockIdx.y * (int)gridDim.z + (int)blockIdx.z) * (int)gridDim.x + (int)blockIdx.x;
-        if (id >= 256 && id < 512 && (int)(gridDim.x * gridDim.y * gridDim.z) >= 768) {
+        const int us = FRIDO_STAGGER_RT ? (d.flags >> 8) & 255 : FRIDO_STAGGER_US;
+        const int min_wg = (FRIDO_STAGGER_RT && ((d.flags >> 16) & 255)) ? ((d.flags >> 16) & 255) * 64 : 768;
+        if (us && id >= 256 && id < 512 && (int)(gridDim.x * gridDim.y * gridDim.z) >= min_wg) {
             const uint64_t t0 = wall_clock64();             // 100 MHz
-            while (wall_clock64() - t0 < (uint64_t)(FRIDO_STAGGER_US * 100)) __builtin_amdgcn_s_sleep(16);
+            while (wall_clock64() - t0 < (uint64_t)(us * 100)) __builtin_amdgcn_s_sleep(16);
         }
     }
     // batch index, optionally two-level (outer x inner, e.g. image x head)
