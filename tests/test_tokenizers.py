@@ -7,7 +7,6 @@ the Rust BertWordPieceTokenizer and BertTokenizerFast, the byte-level BPE agains
 """
 import gzip
 import json
-import os
 
 import pytest
 import torch
