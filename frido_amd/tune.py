@@ -111,15 +111,21 @@ def workspace(device, nbytes, tag=""):
 _rot = [0]
 
 
+def signature(st):
+    """Cache key of a filled FridoGemm descriptor (pointers only as present / absent)."""
+    sig = tuple(getattr(st, f) for f in _SIG_FIELDS) + (bool(st.residual), bool(st.out_f32), bool(st.out_op),
+                                                        bool(st.bias), bool(st.rowvec), bool(st.row_bias))
+    if _lib.active_planes() != "f16":      # (r05) the bf16-pair build: its own choices, never persisted (the pinned cache file is the default build's)
+        sig = sig + (_lib.active_planes(),)
+    return sig
+
+
 def best_tile(st, device, stream):
     """st: a filled FridoGemm ctypes struct (pointers are ignored: scratch buffers are substituted).
     Returns (tile, splitk)."""
     if not ENABLED:
         return 0, 1
-    sig = tuple(getattr(st, f) for f in _SIG_FIELDS) + (bool(st.residual), bool(st.out_f32), bool(st.out_op),
-                                                        bool(st.bias), bool(st.rowvec), bool(st.row_bias))
-    if _lib.active_planes() != "f16":      # (r05) the bf16-pair build: its own choices, never persisted (the pinned cache file is the default build's)
-        sig = sig + (_lib.active_planes(),)
+    sig = signature(st)
     if sig in _cache:
         return _cache[sig]
     if ON_MISS == "static":

@@ -1,0 +1,85 @@
+"""CPU tests of the measurement tools' own logic (no GPU: timers are faked)."""
+import importlib.util
+import os
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "tools", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _st(M, N, K, tile, **kw):
+    d = dict(M=M, N=N, K=K, K2=0, batch=1, nsplit=2, conv=0, tile=tile, splitk=1, up2_phase=0)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_in_context_tuner_keeps_only_clear_wins_and_restores_the_rest():
+    tic = _load("tune_in_context")
+    GEMM, OTHER = 1, 2
+    prog = types.SimpleNamespace(_packed=None, ops=[
+        (GEMM, _st(16384, 3072, 384, 2)), (OTHER, None),            # signature A: tile 7 is 20 % faster in context
+        (GEMM, _st(4096, 576, 576, 1)), (OTHER, None),              # signature B: tile 5 wins by 0.5 % only -> unchanged
+        (GEMM, _st(16384, 3072, 384, 2)), (OTHER, None),            # signature A again
+        (GEMM, _st(1024, 960, 960, 3, splitk=4)),                   # split-K launch: never touched
+        (GEMM, _st(65536, 192, 1728, 20)),                          # fused GroupNorm + conv tile: never touched
+        (GEMM, _st(32, 960, 960, 3)),                               # M < 64: tiles 1 / 2 / 4 are not candidates, tile 6 is "rejected"
+    ])
+    calls = {"n": 0}
+
+    def time_forward():
+        calls["n"] += 1
+        row = []
+        for kind, st in prog.ops:
+            if kind != GEMM:
+                row.append(0.010)
+            elif st.M == 16384:
+                row.append(0.100 if st.tile != 7 else 0.080)
+            elif st.M == 4096:
+                row.append(0.0500 if st.tile != 5 else 0.04975)
+            elif st.M == 32:
+                if st.tile == 6:
+                    raise RuntimeError("rejected")
+                row.append(0.020)
+            else:
+                row.append(0.030)
+        return [[row, row, row]]
+
+    sig = lambda st: (st.M, st.N, st.K)
+    kept, total = tic.tune([prog], time_forward, sig, GEMM, min_gain=0.015, min_share=0.002, log=lambda *_: None)
+    assert [(k[0], k[1], k[2]) for k in kept] == [((16384, 3072, 384), 2, 7)]
+    assert abs(total - (0.2 + 0.05 + 0.03 + 0.03 + 0.02 + 0.03)) < 1e-9
+    tiles = [st.tile for kind, st in prog.ops if kind == GEMM]
+    assert tiles == [7, 1, 7, 3, 20, 3]                              # winners applied, everything else restored
+    assert tic.candidates(prog.ops[6][1]) == [] and tic.candidates(prog.ops[7][1]) == []
+    assert 1 not in tic.candidates(prog.ops[8][1]) and 7 not in tic.candidates(prog.ops[8][1])
+    assert set(tic.candidates(prog.ops[0][1])) == {1, 2, 3, 4, 5, 6, 18, 19}            # (its own tile, now 7, is not a candidate)
+
+
+def test_trace_diff_groups_by_kernel_and_grid(tmp_path, capsys):
+    import csv
+    td = _load("trace_diff")
+    hdr = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z", "Grid_Size_X",
+           "Grid_Size_Y", "Grid_Size_Z"]
+    for name, us in (("a", 150), ("b", 135)):
+        d = tmp_path / name / "x"
+        d.mkdir(parents=True)
+        with open(d / "1_kernel_trace.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(hdr)
+            for i in range(4):
+                w.writerow(["void igemm_kernel<128, 192>(FridoGemm)", 1000 * i, 1000 * i + us * 1000, 256, 1, 1, 256 * 2048, 1, 1])
+            w.writerow(["void igemm_kernel<128, 192>(FridoGemm)", 0, 50000, 256, 1, 1, 256 * 768, 1, 1])
+    agg = td.load(str(tmp_path / "a"))
+    assert agg[("void igemm_kernel<128, 192>(FridoGemm)", 2048, 256)] == [4, 600000]
+    assert agg[("void igemm_kernel<128, 192>(FridoGemm)", 768, 256)] == [1, 50000]
+    import sys
+    sys.argv = ["trace_diff.py", str(tmp_path / "a"), str(tmp_path / "b")]
+    td.main()
+    out = capsys.readouterr().out
+    assert "-0.06" in out and "2048" in out
