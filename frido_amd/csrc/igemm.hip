@@ -42,8 +42,9 @@ int frido_convgn_init();
 #define FRIDO_STAGGER_US 8
 #endif
 // Run-time form of the same (for round 6; -DFRIDO_STAGGER_RT=1 builds only, the shipped library is built with 0 and is bit-identical to
-// the one without this code): the delay in microseconds comes from FridoGemm.flags bits 8..15 (0 = none), the smallest grid it applies
-// to from bits 16..23 in units of 64 workgroups (0 = 768 workgroups).  Python: FRIDO_STAGGER_US / FRIDO_STAGGER_MIN_WG (engine.py).
+// the one without this code): the delay in QUARTER microseconds comes from FridoGemm.flags bits 8..15 (0 = none), the smallest grid it
+// applies to from bits 16..23 in units of 64 workgroups (0 = 768 workgroups), which workgroups wait from bits 24..25.
+// Python: FRIDO_STAGGER_US (a float) / FRIDO_STAGGER_MIN_WG / FRIDO_STAGGER_MODE (engine.py).
 #ifndef FRIDO_STAGGER_RT
 #define FRIDO_STAGGER_RT 0
 #endif
@@ -130,11 +131,17 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     const int m0 = tm * BM, n0 = tn * BN;
     if constexpr (((FRIDO_ABLATE & 1024) || FRIDO_STAGGER_RT) && NW == 4) {
         const int id = ((int)blockIdx.y * (int)gridDim.z + (int)blockIdx.z) * (int)gridDim.x + (int)blockIdx.x;
-        const int us = FRIDO_STAGGER_RT ? (d.flags >> 8) & 255 : FRIDO_STAGGER_US;
+        // run-time form: delay in QUARTER microseconds (a k-step of these tiles is ~1 us: sub-k-step offsets are the interesting ones for
+        // one-round launches), smallest grid in units of 64 workgroups, and which workgroups wait: mode 0 = dispatch ids 256..511 (the
+        // second slot of every CU if the dispatcher deals one workgroup per CU first), mode 1 = every other workgroup of an XCD among
+        // the first 512 (the control: right only if the dispatcher fills a CU's two slots back to back)
+        const int ticks = FRIDO_STAGGER_RT ? ((d.flags >> 8) & 255) * 25 : FRIDO_STAGGER_US * 100;          // 100 MHz
         const int min_wg = (FRIDO_STAGGER_RT && ((d.flags >> 16) & 255)) ? ((d.flags >> 16) & 255) * 64 : 768;
-        if (us && id >= 256 && id < 512 && (int)(gridDim.x * gridDim.y * gridDim.z) >= min_wg) {
-            const uint64_t t0 = wall_clock64();             // 100 MHz
-            while (wall_clock64() - t0 < (uint64_t)(us * 100)) __builtin_amdgcn_s_sleep(16);
+        const int mode = FRIDO_STAGGER_RT ? (d.flags >> 24) & 3 : 0;
+        const bool late = mode == 0 ? (id >= 256 && id < 512) : (id < 512 && ((id >> 3) & 1));
+        if (ticks && late && (int)(gridDim.x * gridDim.y * gridDim.z) >= min_wg) {
+            const uint64_t t0 = wall_clock64();
+            while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(4);
         }
     }
     // batch index, optionally two-level (outer x inner, e.g. image x head)

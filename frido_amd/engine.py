@@ -17,9 +17,10 @@ SIDE_STREAM = os.environ.get("FRIDO_SIDE_STREAM", "0") != "0"   # independent pr
 GEMM_FLAGS = int(os.environ.get("FRIDO_GEMM_FLAGS", "0"))     # FridoGemm.flags A/B switches (include/frido_hip.h)
 # r05 stagger experiment (honoured only by -DFRIDO_STAGGER_RT=1 builds of the library, results unchanged):
 # start delay in microseconds of the second resident slot of a multi-round two-per-CU GEMM launch, and the smallest grid it applies to
-STAGGER_US = int(os.environ.get("FRIDO_STAGGER_US", "0"))
+STAGGER_US = float(os.environ.get("FRIDO_STAGGER_US", "0"))          # quarter-microsecond resolution, at most 63.75
 STAGGER_MIN_WG = int(os.environ.get("FRIDO_STAGGER_MIN_WG", "0"))
-GEMM_FLAGS |= ((STAGGER_US & 255) << 8) | (((STAGGER_MIN_WG // 64) & 255) << 16)
+STAGGER_MODE = int(os.environ.get("FRIDO_STAGGER_MODE", "0"))        # 0: dispatch ids 256..511 wait; 1: every other workgroup of an XCD (control)
+GEMM_FLAGS |= ((int(round(STAGGER_US * 4)) & 255) << 8) | (((STAGGER_MIN_WG // 64) & 255) << 16) | ((STAGGER_MODE & 3) << 24)
 BF16X3 = 2   # nsplit: hi + residual plane, 3 MFMAs per product (≈ fp32 accuracy)
 BF16 = 1     # nsplit: plain bf16 operands
 
