@@ -144,3 +144,38 @@ def test_clip_text_embedder_tokenizes_strings_from_a_local_merge_table(clip_file
     except ImportError:
         with pytest.raises(NotImplementedError, match="FRIDO_CLIP_BPE"):
             FrozenCLIPTextEmbedder(arch=arch)._tokens(["the cat"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# random captions (hypothesis): the restatements against the installed implementations beyond the hand-written cases
+def test_wordpiece_matches_rust_on_random_unicode_captions(bert_vocab):
+    from hypothesis import given, settings, strategies as st
+    from tokenizers import BertWordPieceTokenizer
+    ref = BertWordPieceTokenizer(bert_vocab, lowercase=True)
+    mine = WordPieceTokenizer(bert_vocab)
+    alphabet = st.sampled_from(list("abcdefgxyzTHECATS0159 \t\n,.!?'()-$~^`|éÉüñçÅ人日本́  \x07​�_[]#"))
+    words = st.sampled_from(["the", "cat", "dog", "sitting", "unbelievable", "standing", "people", "trees", "[MASK]", "[SEP]", "##ing", "café"])
+
+    @settings(max_examples=300, deadline=None, database=None)
+    @given(st.lists(st.one_of(st.text(alphabet, max_size=12), words), max_size=12).map(" ".join))
+    def check(caption):
+        assert [mine.cls] + mine.encode(caption) + [mine.sep] == ref.encode(caption).ids, repr(caption)
+
+    check()
+
+
+def test_clip_bpe_matches_hf_on_random_ascii_captions(clip_files):
+    from hypothesis import given, settings, strategies as st
+    from transformers import CLIPTokenizer
+    merges, gz, vj = clip_files
+    hf = CLIPTokenizer(vocab=vj, merges=merges)
+    mine = ClipBPETokenizer(gz)
+    alphabet = st.sampled_from(list("abcdeghimnorstTHECATS0129 ,.!?'-"))
+    words = st.sampled_from(["the", "cat", "cat's", "dog", "sitting", "on", "mat", "tree", "trees", "12", "!!!", "it's", "we're", "i'd"])
+
+    @settings(max_examples=200, deadline=None, database=None)
+    @given(st.lists(st.one_of(st.text(alphabet, max_size=10), words), max_size=10).map(" ".join))
+    def check(caption):
+        assert [mine.sot] + mine.encode(caption) + [mine.eot] == hf(caption)["input_ids"], repr(caption)
+
+    check()
