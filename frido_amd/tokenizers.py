@@ -119,6 +119,8 @@ class WordPieceTokenizer:
     def __call__(self, text, max_length=77):
         """[CLS] ids [SEP], truncated to max_length (the [SEP] survives), padded with [PAD]: what the reference's call
         (modules.py:69-70: truncation=True, padding="max_length") returns as `input_ids`."""
+        if max_length < 2:
+            raise ValueError("max_length must leave room for [CLS] and [SEP]")
         texts = [text] if isinstance(text, str) else list(text)
         out = torch.full((len(texts), max_length), self.pad, dtype=torch.long)
         for i, t in enumerate(texts):
