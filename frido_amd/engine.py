@@ -291,7 +291,12 @@ class Prog:
         if not tile and self.device.type == "cuda":
             from . import tune
             st = self.ops[-1][1]
-            st.tile, st.splitk = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
+            choice = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
+            st.tile, st.splitk = choice[0], choice[1]
+            if len(choice) > 2 and choice[2] and not STAGGER_US:
+                # (r05, for round 6) a pinned per-signature start delay in quarter microseconds (tools/tune_in_context.py --stagger):
+                # FridoGemm.flags bits 8..15, honoured only by -DFRIDO_STAGGER_RT=1 builds; FRIDO_STAGGER_US overrides it globally
+                st.flags = (st.flags & ~0xFF00) | ((int(choice[2]) & 255) << 8)
             if st.splitk > 1:
                 st.sk_mode = tune.SK_MODE
                 if not st.sk_mode:

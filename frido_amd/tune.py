@@ -122,7 +122,8 @@ def signature(st):
 
 def best_tile(st, device, stream):
     """st: a filled FridoGemm ctypes struct (pointers are ignored: scratch buffers are substituted).
-    Returns (tile, splitk)."""
+    Returns (tile, splitk) -- or (tile, splitk, start delay in quarter microseconds) for a signature whose pinned cache entry carries
+    one (written by tools/tune_in_context.py --stagger; this function's own timing never produces the third element)."""
     if not ENABLED:
         return 0, 1
     sig = signature(st)

@@ -14,7 +14,7 @@ def _load(name):
 
 
 def _st(M, N, K, tile, **kw):
-    d = dict(M=M, N=N, K=K, K2=0, batch=1, nsplit=2, conv=0, tile=tile, splitk=1, up2_phase=0)
+    d = dict(M=M, N=N, K=K, K2=0, batch=1, nsplit=2, conv=0, tile=tile, splitk=1, up2_phase=0, flags=0)
     d.update(kw)
     return types.SimpleNamespace(**d)
 
@@ -59,6 +59,48 @@ def test_in_context_tuner_keeps_only_clear_wins_and_restores_the_rest():
     assert tic.candidates(prog.ops[6][1]) == [] and tic.candidates(prog.ops[7][1]) == []
     assert 1 not in tic.candidates(prog.ops[8][1]) and 7 not in tic.candidates(prog.ops[8][1])
     assert set(tic.candidates(prog.ops[0][1])) == {1, 2, 3, 4, 5, 6, 18, 19}            # (its own tile, now 7, is not a candidate)
+
+
+def test_in_context_tuner_sweeps_the_start_delay_of_eligible_launches_only():
+    tic = _load("tune_in_context")
+    GEMM = 1
+    prog = types.SimpleNamespace(_packed=None, ops=[
+        (GEMM, _st(16384, 3072, 384, 2)),           # 2048 workgroups of a 4-wave tile: eligible; 6 us (24 quarter-us) is best in context
+        (GEMM, _st(4096, 576, 576, 1)),             # 160 workgroups: below the threshold, never delayed
+        (GEMM, _st(16384, 384, 1536, 18)),          # 8-wave tile: no second resident slot
+    ])
+
+    def time_forward():
+        row = []
+        for _, st in prog.ops:
+            q = (st.flags >> 8) & 255
+            if st.M == 16384 and st.N == 3072:
+                row.append(0.100 - 0.0005 * q if q <= 24 else 0.100)
+            else:
+                assert q == 0
+                row.append(0.050)
+        return [[row, row]]
+
+    kept, _ = tic.tune([prog], time_forward, lambda st: (st.M, st.N, st.K), GEMM, min_gain=0.015, stagger=(8, 16, 24, 32, 48), min_wg=512,
+                       log=lambda *_: None)
+    assert [(k[0], k[1], k[2], k[5]) for k in kept] == [((16384, 3072, 384), 2, 2, 24)]
+    assert [(st.flags >> 8) & 255 for _, st in prog.ops] == [24, 0, 0]
+    assert tic.workgroups(prog.ops[0][1]) == 2048 and tic.workgroups(prog.ops[2][1]) is None
+
+
+def test_pinned_cache_entry_may_carry_a_start_delay(monkeypatch):
+    """engine.Prog.gemm applies the optional third element of a tuner choice to FridoGemm.flags bits 8..15 (round-6 plumbing);
+    a two-element choice (every entry of today's pinned cache) leaves the flags alone."""
+    import torch
+    from frido_amd import engine, tune
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: types.SimpleNamespace(cuda_stream=0))
+    for choice, want in (((2, 1, 24), 24 << 8), ((2, 1), 0), ((1, 4, 0), 0)):
+        monkeypatch.setattr(tune, "best_tile", lambda st, dev, stream, c=choice: c)
+        monkeypatch.setattr(tune, "workspace_for", lambda st, dev, tag="": 0)
+        p = engine.Prog(torch.device("cuda"), 2)
+        p.gemm(16384, 3072, 384, (0x1000, 64), (0x2000, 64), out_f32=0x3000, ldo=3072)
+        st = p.ops[-1][1]
+        assert (st.tile, st.splitk) == choice[:2] and st.flags == (engine.GEMM_FLAGS | want)
 
 
 def test_trace_diff_groups_by_kernel_and_grid(tmp_path, capsys):
