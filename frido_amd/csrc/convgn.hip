@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    stagger_one_per_cu(d.flags);
     const int W = d.Ws, H = d.Hs, HW = H * W;
     const int R = BM / W, PW = W + 2, PS = (R + 2) * PW;
     const int img = m0 / HW, y0 = (m0 - img * HW) / W;

@@ -45,9 +45,7 @@ int frido_convgn_init();
 // the one without this code): the delay in QUARTER microseconds comes from FridoGemm.flags bits 8..15 (0 = none), the smallest grid it
 // applies to from bits 16..23 in units of 64 workgroups (0 = 768 workgroups), which workgroups wait from bits 24..25.
 // Python: FRIDO_STAGGER_US (a float) / FRIDO_STAGGER_MIN_WG / FRIDO_STAGGER_MODE (engine.py).
-#ifndef FRIDO_STAGGER_RT
-#define FRIDO_STAGGER_RT 0
-#endif
+// (FRIDO_STAGGER_RT itself: igemm_shared.h, next to the one-workgroup-per-CU form of the experiment)
 #ifndef FRIDO_X3_PIPE_ALL
 #define FRIDO_X3_PIPE_ALL 0      // 1: also run the six-n-tile bf16x3 tiles (128 x 192, 64 x 192) on the virtual-k-step loop
 #endif
@@ -144,6 +142,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
             while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(4);
         }
     }
+    if constexpr (NW == 8) stagger_one_per_cu(d.flags);
     // batch index, optionally two-level (outer x inner, e.g. image x head)
     int zo = blockIdx.y, zi = 0;
     if (d.batch_inner > 1) {

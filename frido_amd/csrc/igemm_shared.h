@@ -29,6 +29,26 @@ __device__ __forceinline__ int xcd_item(int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// r05 experiment for round 6 (-DFRIDO_STAGGER_RT=1 builds only; the shipped library is built without and contains none of it): the
+// ONE-workgroup-per-CU kernels (8-wave igemm tiles, the fused GroupNorm + conv kernel) run a launch's prologue loads, its k-loop and its
+// epilogue stores chip-wide at the same time.  FridoGemm.flags bit 26 lets the odd XCDs (dispatch id & 1) start bits 8..15 quarter
+// microseconds late, so that one half's HBM phases fall under the other half's MFMA phase.  Results unchanged.
+#ifndef FRIDO_STAGGER_RT
+#define FRIDO_STAGGER_RT 0
+#endif
+__device__ __forceinline__ void stagger_one_per_cu(int flags) {
+#if FRIDO_STAGGER_RT
+    const int ticks = ((flags >> 8) & 255) * 25;           // 100 MHz
+    const int id = ((int)blockIdx.y * (int)gridDim.z + (int)blockIdx.z) * (int)gridDim.x + (int)blockIdx.x;
+    if (((flags >> 26) & 1) && ticks && (id & 1) && id < 256) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(4);
+    }
+#else
+    (void)flags;
+#endif
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {

@@ -20,7 +20,9 @@ GEMM_FLAGS = int(os.environ.get("FRIDO_GEMM_FLAGS", "0"))     # FridoGemm.flags 
 STAGGER_US = float(os.environ.get("FRIDO_STAGGER_US", "0"))          # quarter-microsecond resolution, at most 63.75
 STAGGER_MIN_WG = int(os.environ.get("FRIDO_STAGGER_MIN_WG", "0"))
 STAGGER_MODE = int(os.environ.get("FRIDO_STAGGER_MODE", "0"))        # 0: dispatch ids 256..511 wait; 1: every other workgroup of an XCD (control)
-GEMM_FLAGS |= ((int(round(STAGGER_US * 4)) & 255) << 8) | (((STAGGER_MIN_WG // 64) & 255) << 16) | ((STAGGER_MODE & 3) << 24)
+STAGGER_8W = int(os.environ.get("FRIDO_STAGGER_8W", "0"))            # 1: the one-workgroup-per-CU kernels too (odd XCDs start late; igemm_shared.h)
+GEMM_FLAGS |= (((int(round(STAGGER_US * 4)) & 255) << 8) | (((STAGGER_MIN_WG // 64) & 255) << 16) | ((STAGGER_MODE & 3) << 24)
+               | ((STAGGER_8W & 1) << 26))
 BF16X3 = 2   # nsplit: hi + residual plane, 3 MFMAs per product (≈ fp32 accuracy)
 BF16 = 1     # nsplit: plain bf16 operands
 

@@ -26,3 +26,7 @@ cat $OUT/r06_stagger_min_wg_sweep.txt
 # (d) control: the other placement model (every other workgroup of an XCD waits) at the best delay
 ( FRIDO_STAGGER_US=$BEST FRIDO_STAGGER_MODE=1 run "stagger_us=$BEST mode=1"; FRIDO_STAGGER_US=$BEST run "stagger_us=$BEST mode=0" ) > $OUT/r06_stagger_mode_control.txt 2>&1
 cat $OUT/r06_stagger_mode_control.txt
+# (e) the one-workgroup-per-CU kernels (8-wave igemm tiles, fused GroupNorm + conv): odd XCDs start late (flags bit 26)
+( for us in 0 4 8 12; do FRIDO_STAGGER_US=$us FRIDO_STAGGER_8W=1 FRIDO_STAGGER_MIN_WG=4096 run "8w stagger_us=$us"; done
+  FRIDO_STAGGER_US=$BEST FRIDO_STAGGER_8W=1 run "8w + 4-wave stagger_us=$BEST" ) > $OUT/r06_stagger_8w.txt 2>&1
+cat $OUT/r06_stagger_8w.txt
