@@ -282,6 +282,16 @@ def whole_step(S, images_per_s, world):
             "frac": round(t / (2500.0 * world), 4)}
 
 
+def config4_record(total, per_gpu, world, seconds, ddim_steps, stub=False):
+    """`extra.config4_B32_per_gpu` of an N > 1 line: BASELINE config 4's per-GPU shard (32 images) through the same sharded job."""
+    rec = {"workload": f"layout2i f8f4, batch {total} sharded {world} x {per_gpu} (BASELINE config 4 is 8 x 32 = 256), DDIM-{ddim_steps} x 2 stages + decode "
+                       "+ one all-gather of the images", "global_batch": total, "per_gpu_batch": per_gpu, "n_gpus": world, "timed_passes": 1,
+           "value": round(total / seconds, 4), "unit": "images/s", "ms_per_step": round(1e3 * seconds, 2)}
+    if stub:
+        rec["stub"] = True
+    return rec
+
+
 def relaunch(n):
     """Re-exec this command line under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1, a free port)."""
     import socket
@@ -327,6 +337,18 @@ def stub_main(args, dist, use_dist, world, rank):
         dist.all_gather(allt, torch.tensor([dt], dtype=torch.float64))
         per_rank = [float(t.item()) for t in allt]
         dt = max(per_rank)
+    cfg4 = None
+    if world > 1 and B == 16 and not args.no_config4:        # the config-4 pass of the real N > 1 job (32 per GPU), same collective
+        tot4 = 32 * world
+        lo4, hi4 = shard_range(tot4, rank, world)
+        if use_dist:
+            dist.barrier()
+        t4 = time.perf_counter()
+        img4 = all_gather_images(torch.arange(lo4, hi4, dtype=torch.float32).view(-1, 1, 1, 1).expand(hi4 - lo4, 3, 8, 8).contiguous(), total=tot4)
+        if use_dist:
+            dist.barrier()
+        assert torch.equal(img4[:, 0, 0, 0], torch.arange(tot4, dtype=torch.float32))
+        cfg4 = config4_record(tot4, 32, world, max(time.perf_counter() - t4, 1e-6), args.ddim_steps, stub=True)
     k_last = args.warmup + args.steps - 1
     assert img.shape == (total, 3, 8, 8) and torch.equal(img[:, 0, 0, 0], 1000.0 * k_last + torch.arange(total, dtype=torch.float32))
     if rank == 0:
@@ -334,9 +356,11 @@ def stub_main(args, dist, use_dist, world, rank):
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "stub", "data": "stub", "stub": True,
-                          "config": {"workload": "STUB (FRIDO_BENCH_STUB=1): launcher / shard / timing test on CPU over gloo, not a measurement",
+                          "config": {"workload": "STUB (FRIDO_BENCH_STUB=1): launcher / shard / timing test on CPU over gloo, not a measurement"
+                                                 + ("; extra.config4_B32_per_gpu: the same job at 32 per GPU" if cfg4 else ""),
                                      "global_batch": total, "parallelism": f"dp{world}"},
-                          "per_rank_ms_per_step": [round(1e3 * t / args.steps, 2) for t in per_rank]}))
+                          "per_rank_ms_per_step": [round(1e3 * t / args.steps, 2) for t in per_rank],
+                          **({"extra": {"config4_B32_per_gpu": cfg4}} if cfg4 else {})}))
     if use_dist:
         dist.destroy_process_group()
 
@@ -357,6 +381,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short passes of BASELINE configs 3 (t2i f16f8, B = 32, PLMS-100 + CFG 1.5) and 5 (512^2, 3 scales, B = 8) "
                          "that the N = 1 line carries in `extra.other_configs`")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="N > 1 only: skip the extra pass at 32 images per GPU (BASELINE config 4's shard) reported in extra.config4_B32_per_gpu")
     ap.add_argument("--no-bf16-extra", "--no-parity-mode", dest="no_bf16_extra", action="store_true",
                     help="skip the extra bf16 (throughput-mode) pass at N = 1")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -420,8 +446,12 @@ def main():
     ctx = torch.from_numpy(ctx_all[lo:hi]).to(dev)
 
     def one_step(k):
+        # check_status=False (r06, advisor): the sticky numerics word is NOT read-and-cleared per pass -- that put a batch of synchronous
+        # symbol copies inside the timed loop and left `status_flags` below always 0; it is read ONCE after all passes instead
         return sample_images(model, ctx, S=args.ddim_steps, eta=1.0, seed=1000 + k, sample0=lo, noise="philox", total=total,
-                             gather_dtype=args.image_dtype)
+                             gather_dtype=args.image_dtype, check_status=False)
+
+    _lib.status_flags(clear=True)
 
     for k in range(args.warmup):
         one_step(k)
@@ -458,6 +488,33 @@ def main():
     dt_loop = time.perf_counter() - t0
     assert (bool(torch.isfinite(z_chk).all()) and float(z_chk.std()) > 0.05 and int(img.max()) > int(img.min())) or debug_env, "degenerate samples"
 
+    status_after_timed = _lib.status_flags()          # every pass above ran with check_status=False: this is the word of ALL of them
+
+    # (r06, r05 verdict next 8) BASELINE config 4 is "batch 256 sharded over 8 GPUs" = 32 per GPU; the driver's scaling spelling
+    # (--gpus N, default batch 16) would never run it, so every N > 1 job adds ONE warm + ONE timed pass at 32 per GPU (same model,
+    # same collective) and reports it in `extra.config4_B32_per_gpu`.  --no-config4 skips it; N = 1 has it as tools' --batch 32 line.
+    cfg4 = None
+    if world > 1 and B == 16 and not args.no_config4:
+        B4 = 32
+        tot4 = B4 * world
+        lo4, hi4 = shard_range(tot4, rank, world)
+        ctx4 = torch.from_numpy(synth.seeded_normal("bench:ctx", (tot4, 26, 640))[lo4:hi4]).to(dev)
+        step4 = lambda k: sample_images(model, ctx4, S=args.ddim_steps, eta=1.0, seed=3000 + k, sample0=lo4, noise="philox", total=tot4,
+                                        gather_dtype=args.image_dtype, check_status=False)
+        step4(0)
+        fence()
+        t0 = time.perf_counter()
+        img4 = step4(1)
+        fence()
+        d4 = time.perf_counter() - t0
+        if use_dist:
+            t4 = torch.tensor([d4], device=dev, dtype=torch.float64)
+            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+            d4 = float(t4.item())
+        assert img4.shape[0] == tot4
+        cfg4 = config4_record(tot4, B4, world, d4, args.ddim_steps)
+        del img4, ctx4
+
     if rank == 0:
         rt = model.model.diffusion_model.runtime()
         eng = next(iter(rt._sampler_engines.values()))
@@ -489,7 +546,8 @@ def main():
             "data": "synthetic (random-init weights from the deterministic filler, N(0,1) context, Philox x_T/noise)",
             "config": {"workload": f"layout2i f8f4 (configs/frido/layout2i/frido_f8f4_coco_seg.yaml), per-GPU batch {B}, "
                                    f"DDIM-{args.ddim_steps} eta=1.0 x 2 stages + MS-VQGAN decode"
-                                   + f" to {args.image_dtype} images" + (f", RCCL all-gather of the {args.image_dtype} images" if world > 1 else ""),
+                                   + f" to {args.image_dtype} images" + (f", RCCL all-gather of the {args.image_dtype} images" if world > 1 else "")
+                                   + ("; extra.config4_B32_per_gpu: the same job at 32 per GPU (BASELINE config 4's shard), one timed pass" if cfg4 else ""),
                        "global_batch": total, "denoiser_forwards_per_step": 2 * args.ddim_steps, "parallelism": f"dp{world}",
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("FRIDO_") and k != "FRIDO_TUNE_CACHE"}},
             "roofline": roof,
@@ -498,12 +556,14 @@ def main():
             "whole_step": whole_step(args.ddim_steps, total * args.steps / dt, world),
             "loop_only_value": round(total / dt_loop, 4),         # sample_diffusion.py's `throughput`: sampler loop without decode
             "per_rank_ms_per_step": [round(1e3 * t / args.steps, 2) for t in per_rank],
-            # sticky numerics word of the library after all passes (frido_status_flags): 0 = no fp16 operand plane saturated, no
-            # normalisation statistic was NaN / inf anywhere in the timed work
-            "status_flags": _lib.status_flags(),
+            # sticky numerics word of the library, read ONCE after the warm-up, timed and loop-only passes, none of which cleared it
+            # (frido_status_flags): 0 = no fp16 operand plane saturated, no normalisation statistic was NaN / inf anywhere in that work
+            "status_flags": status_after_timed,
         }
         if debug_env:
             out["debug_work_skipped"] = True
+        if cfg4:
+            out.setdefault("extra", {})["config4_B32_per_gpu"] = cfg4
         if world == 1 and args.precision == "bf16x3" and not args.no_bf16_extra:
             # the same workload in plain bf16 (one plane, one MFMA pass): a THROUGHPUT mode that fails the north star's <= 1e-3
             # tolerance (its measured error is in the committed E2E record) -- reported for reference, never as `value`
@@ -549,12 +609,17 @@ def main():
                     others[key] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()
             out.setdefault("extra", {})["other_configs"] = others
+            # (r06) the two values again as a flat top-level dict: a record that keeps only the first level of the line still holds them
+            out["other_configs_images_per_s"] = {k: v.get("value", v.get("error")) for k, v in others.items()}
         if world == 1 and not args.no_cpu_baseline:
             # B in {1, 4} x {8, 16, 32, all physical cores} torch threads; `cores` = the best point's thread count
             try:      # (r05, advisor) a failure of the CPU leg must not lose the GPU measurement above
                 out["cpu_baseline"] = cpu_baseline(args.cpu_threads, full_ddim50=not args.no_cpu_ddim50)
             except Exception as e:      # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "kind": "port", "value": None, "unit": "images/s", "cores": 0}
+        # key order of the line: the flat summary keys first, the long nested blocks (`extra`, `cpu_baseline`) last
+        tail = [k for k in ("roofline", "extra", "cpu_baseline") if k in out]
+        out = {**{k: v for k, v in out.items() if k not in tail}, **{k: out[k] for k in tail}}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -332,6 +332,13 @@ extern "C" int frido_status_flags(uint32_t* flags, int32_t clear) {
         frido_set_error("frido_status_flags: null pointer");
         return FRIDO_EINVAL;
     }
+    // (r06, advisor) the per-file words are read with null-stream symbol copies, which do NOT wait for kernels on non-blocking streams
+    // (how torch creates its side streams): drain the device first, so that the word read -- and cleared -- is the word of everything
+    // launched before this call
+    if (hipDeviceSynchronize() != hipSuccess) {
+        frido_set_error("frido_status_flags: hipDeviceSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        return FRIDO_EHIP;
+    }
     unsigned all = 0;
     for (auto fn : status_words()) {
         unsigned w = 0;

@@ -519,7 +519,13 @@ class FridoDiffusion(_Base):
         if cond_stage_config == "__is_unconditional__":
             conditioning_key = None
         self.model = DiffusionWrapper(unet_config, conditioning_key)
-        self.specify_channels = specify_channels
+        if specify_channels:
+            # ddim.py:207-209,250-251,270-271 / plms.py:216-217,263-264,280-281: the first specify_channels[0] channels of the latent are held
+            # fixed through every update (their eps zeroed, pred_x0 and x_prev copied from x) -- an option no shipped config sets (default:
+            # the empty list).  The HIP sampler step has no such blend: refusing beats storing the option and ignoring it (r05 verdict).
+            raise NotImplementedError("specify_channels: holding the leading channels fixed (ddim.py:207-209,250-251,270-271) is not provided on the HIP path "
+                                      "(no shipped Frido config sets it)")
+        self.specify_channels = []
         self.unet_config = unet_config
         self.use_split_head = unet_config["params"].get("use_split_head", False)
         self.split_embed_dim_list = unet_config["params"].get("split_embed_dim_list", [])

@@ -55,10 +55,31 @@ def _fill_heavy(name, shape, rng, leaf):
     return (0.5 * rng.standard_normal(shape)).astype(np.float32)
 
 
+_CACHE = None      # {(name, shape, profile): array} when enable_cache() was called (the GPU suite: tests/conftest.py)
+
+
+def enable_cache():
+    """Memoise fill_tensor for the life of the process.  The filler is a pure function of (name, shape, profile) and costs ~20 s per
+    full-size model on one core; the GPU suite builds the same models dozens of times.  Callers only ever COPY the arrays."""
+    global _CACHE
+    if _CACHE is None:
+        _CACHE = {}
+
+
 def fill_tensor(name, shape, profile=None):
     """float32 array for parameter `name` (a state_dict key) of `shape`.  profile None: the fan-in-scaled N(0, sigma) filler every
     fixture of rounds 1-4 uses; "heavy": the trained-checkpoint-like dynamic range of _fill_heavy."""
     shape = tuple(int(s) for s in shape)
+    if _CACHE is not None:
+        key = (name, shape, profile)
+        if key not in _CACHE:
+            arr = _fill_tensor(name, shape, profile)
+            _CACHE[key] = arr
+        return _CACHE[key]
+    return _fill_tensor(name, shape, profile)
+
+
+def _fill_tensor(name, shape, profile):
     rng = _rng(name if profile is None else f"{profile}:{name}")
     leaf = name.rsplit(".", 1)[-1]
     if len(shape) == 0:

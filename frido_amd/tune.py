@@ -41,10 +41,24 @@ def _lib_tag():
     mode = f"+sk{SK_MODE}" if SK_MODE else ""       # tiles tuned under another split-K reduction are not comparable
     try:
         import hashlib
-        with open(_lib.LIB_PATHS[_lib.active_planes()], "rb") as f:      # content hash: two builds of equal size must not share pinned tiles
+        # content hash of the DEFAULT (fp16-pair) build: two builds of equal size must not share pinned tiles.  (r06, advisor) NOT the
+        # active plane format's file -- the cache file only ever holds the default build's entries (bf16-pair choices are never
+        # persisted), and _load_cache runs once, at the first GEMM a process plans: were that a bf16-pair model, the pinned file would be
+        # rejected for the whole process and could be overwritten at exit
+        with open(_lib.LIB_PATHS["f16"], "rb") as f:
             return hashlib.sha256(f.read()).hexdigest()[:16] + mode
     except OSError:
         return "?"
+
+
+def cache_is_pinned_for_this_library():
+    """True when FRIDO_TUNE_CACHE names a file whose library tag is this build's (tests: are the benchmark's tiles in force?)."""
+    if not CACHE_FILE or not os.path.exists(CACHE_FILE):
+        return False
+    try:
+        return json.load(open(CACHE_FILE)).get("lib") == _lib_tag()
+    except (OSError, ValueError):
+        return False
 
 
 def _load_cache():

@@ -39,7 +39,7 @@ typedef uint16_t frido_bf16;
  * operands became fp16 pairs (frido_x3_plane_format() == 1).  3 (r04): FridoGemm grew at its END (out_u8 / ldu8 / u8_mode, the fused
  * GroupNorm-apply input gn_*), two-plane operand producers saturate at +-65504.  4 (r04): FridoGemm.sk_mode 2 + FridoGnApply.sk_* at the
  * struct's END (a split-K GEMM's reduction finished by the GroupNorm launch that consumes its output).  5 (r05): FridoAttnSmall.skip_act_store
- * at the struct's END; frido_status_flags / frido_status_clear (sticky saturation / non-finite flags). */
+ * at the struct's END; frido_status_flags(&word, clear) (sticky saturation / non-finite flags; clear = 1 resets them). */
 #define FRIDO_ABI_VERSION 5
 #define FRIDO_SPLITK_HEADER_BYTES 65536     /* the ticket header at the start of a split-K workspace; partial sums follow: [splitk][M][N] f32 */
 

@@ -12,6 +12,11 @@ sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU check")
+    config.addinivalue_line("markers", "gate: the <= 3-minute GPU subset that validates a changed binary (pytest -m 'gpu and gate'; README)")
+    # (r06) the deterministic weight filler is a pure function of (name, shape, profile): memoise it for the session -- the GPU suite
+    # builds the same full-size models dozens of times at ~20 s of single-core numpy each
+    from frido_amd import synth
+    synth.enable_cache()
 
 # The GPU suite runs on the tiles the BENCHMARK runs on: the committed, library-hash-keyed tile cache (profiles/tune_cache.json,
 # written by `bench.py --retune`) is read-only here, so a GEMM signature the benchmark uses gets the benchmark's tile in every

@@ -138,6 +138,21 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stdout + bad.stderr      # a mismatch is an error message, not a traceback
 
 
+def test_bench_n_gt_1_line_carries_the_config4_pass():
+    """(r06) BASELINE config 4 is 256 images over 8 GPUs = 32 per GPU; the driver's scaling spelling runs the default 16 per GPU, so every
+    N > 1 job adds one pass at 32 per GPU and reports it as `extra.config4_B32_per_gpu` (named in config.workload).  Stub job over gloo:
+    the record's arithmetic and the opt-out."""
+    line = _bench_line(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    c4 = line["extra"]["config4_B32_per_gpu"]
+    assert c4["per_gpu_batch"] == 32 and c4["global_batch"] == 64 and c4["n_gpus"] == 2 and c4["value"] > 0 and c4["unit"] == "images/s"
+    assert abs(c4["value"] - 64 / (c4["ms_per_step"] * 1e-3)) / c4["value"] < 1e-2 and "config4_B32_per_gpu" in line["config"]["workload"]
+    assert line["config"]["global_batch"] == 32                      # the headline workload is still 16 per GPU
+    off = _bench_line(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-config4"], {})
+    assert "extra" not in off
+    other = _bench_line(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "5"], {})       # not the default batch: not config 4's job
+    assert "extra" not in other
+
+
 def test_bench_refuses_cleanly_when_the_node_has_fewer_devices_than_ranks():
     """r05: `python bench.py --gpus 2` on a node with fewer than 2 HIP devices (this container: none) prints ONE message and exits
     with a non-zero code before any process group or launcher exists -- no traceback, no hang at a rendezvous."""

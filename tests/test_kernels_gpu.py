@@ -495,6 +495,7 @@ def test_attention_core_stream_output(nsplit, B, Nq, Nk, d):
         assert not hasattr(o, "op_copy")
 
 
+@pytest.mark.gate
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("B,Nq,Nk,d", [(2, 1024, 1024, 384),      # U-Net 32x32 plane
                                        (3, 256, 256, 576),        # U-Net 16x16 plane (4-wave variant, d > 512)
@@ -575,6 +576,7 @@ def test_fused_geglu_projection(nsplit, M, C):
     assert _relerr(o.to_f32().cpu(), h * F.gelu(g)) < _tol(nsplit)
 
 
+@pytest.mark.gate
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("out", ["f32", "op"])
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19])
@@ -913,6 +915,7 @@ GN_CONV_CASES = [
 ]
 
 
+@pytest.mark.gate
 @pytest.mark.parametrize("case", GN_CONV_CASES)
 def test_gn_conv_fused(case):
     """csrc/convgn.inc: GroupNorm(32) [+ SPADE] + SiLU applied INSIDE the 3x3 conv that consumes it (+ the 1x1 skip conv of the raw
@@ -1009,6 +1012,7 @@ def test_gn_conv_fused(case):
         assert _relerr(parts[:, :, 0], blocks.sum(1)) < 1e-5 and _relerr(parts[:, :, 1], (blocks ** 2).sum(1)) < 1e-5
 
 
+@pytest.mark.gate
 @pytest.mark.parametrize("W,C1,C2,Cout_prev,splitk,spade,resid,dead,B", [(16, 576, 0, 576, 4, False, False, False, 16), (8, 960, 0, 960, 8, True, True, False, 16),
                                                                          (16, 384, 192, 384, 3, False, True, False, 16), (8, 960, 0, 960, 5, False, False, True, 16),
                                                                          # r05: the shapes of BASELINE config 3 at its batch (CFG: 64 rows): 8 x 8 x 576 and 4 x 4 x 960

@@ -25,11 +25,37 @@ def _rel(got, ref):
     return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max())
 
 
-def _unet(cfg):
+# (r06) Models a test only READS are built once per session: the full-size layout2i model costs ~25 s of host time per build (575 M
+# parameters through the numpy filler, plan algebra in float64, packed weight upload), and a dozen tests want the same one.  Tests that
+# change weights / scale factors / precision build their own (`_frido`, `_unet`, `_vq` without `shared`).
+_SHARED = {}
+
+
+def _shared(key, make):
+    if key not in _SHARED:
+        _SHARED[key] = make()
+    return _SHARED[key]
+
+
+def _pairs():
+    """{id(unet cfg) or id(vq cfg): (unet cfg, vq cfg)} of the full-size configurations whose parts come out of one shared model."""
+    from golden_cfg import UNET_512, VQ_512
+    out = {}
+    for u, v in ((UNET_FULL, VQ_FULL), (UNET_512, VQ_512)):
+        out[id(u)] = out[id(v)] = (u, v)
+    return out
+
+
+def _unet(cfg, shared=False):
     from frido_amd.models import PyUNetModel
-    m = PyUNetModel(**cfg)
-    fill_module(m, "model.diffusion_model.")
-    return m.cuda().eval()
+    if shared and id(cfg) in _pairs():       # the denoiser of the shared full-size model: same parameter names, same filler
+        return _frido(*_pairs()[id(cfg)], precision="bf16x3", shared=True).model.diffusion_model
+
+    def make():
+        m = PyUNetModel(**cfg)
+        fill_module(m, "model.diffusion_model.")
+        return m.cuda().eval()
+    return _shared(("unet", id(cfg)), make) if shared else make()
 
 
 @pytest.mark.parametrize("name,cfg", [("unet_small", UNET_SMALL), ("unet_small3", UNET_SMALL3), ("unet_small_d2", UNET_SMALL_D2)])
@@ -70,9 +96,10 @@ def test_unet_forward_bf16_mode_within_bf16_tolerance():
     assert _rel(e, g["eps_1"]) < 5e-2
 
 
+@pytest.mark.gate
 def test_unet_full_width_forward_matches_reference_golden():
     g = golden("unet_full")
-    m = _unet(UNET_FULL)
+    m = _unet(UNET_FULL, shared=True)
     x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
     for s in range(2):
         e = m(x[:, :3 * (s + 1)].contiguous(), torch.from_numpy(g[f"t_{s}"]).cuda(), context=ctx, stage=s)
@@ -99,11 +126,16 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 5, 64), stage=0)
 
 
-def _vq(cfg):
+def _vq(cfg, shared=False):
     from frido_amd.models import VQModelInterface
-    m = VQModelInterface(**cfg, lossconfig=dict(target="taming.modules.losses.DummyLoss"))
-    fill_module(m, "first_stage_model.")
-    return m.cuda().eval()
+    if shared and id(cfg) in _pairs():
+        return _frido(*_pairs()[id(cfg)], precision="bf16x3", shared=True).first_stage_model
+
+    def make():
+        m = VQModelInterface(**cfg, lossconfig=dict(target="taming.modules.losses.DummyLoss"))
+        fill_module(m, "first_stage_model.")
+        return m.cuda().eval()
+    return _shared(("vq", id(cfg)), make) if shared else make()
 
 
 def test_vq_decode_matches_reference_golden():
@@ -207,9 +239,10 @@ def test_sample_images_uint8_gather_matches_float_path():
         sample_images(model, c, gather_dtype="int8", **kw)
 
 
+@pytest.mark.gate
 def test_vq_full_width_decode_matches_reference_golden():
     g = golden("vq_full")
-    m = _vq(VQ_FULL)
+    m = _vq(VQ_FULL, shared=True)
     h = torch.from_numpy(g["h"]).cuda()
     dec, code = m.decode(h, return_code=True)
     flips = (np.asarray(code) != g["code"]).mean()
@@ -328,8 +361,10 @@ def test_full_pipeline_with_cond_stage_and_get_input():
     assert _rel(samples, g["ddim_eta1_samples"]) < 1e-3
 
 
-def _frido(ucfg, vcfg, precision=None):
+def _frido(ucfg, vcfg, precision=None, shared=False):
     from frido_amd.models import instantiate_from_config
+    if shared:
+        return _shared(("frido", id(ucfg), id(vcfg), precision), lambda: _frido(ucfg, vcfg, precision))
     cfg = frido_cfg(dict(ucfg, precision=precision), dict(vcfg, precision=precision), BERT_SMALL)
     cfg["cond_stage_config"] = "__is_unconditional__"   # conditioning tensors come from the golden (cond stage = SURVEY §8f)
     cfg["conditioning_key"] = "crossattn"
@@ -622,7 +657,7 @@ def _record(tag, rep):
         json.dump(blob, f, indent=1, sort_keys=True)
 
 
-def _oracle_flip_counts(g, run, S, threads=(1, 16)):
+def _oracle_flip_counts(g, run, S, threads=(16,)):
     """What the ORACLE itself does on this fixture: the CPU restatement (fp32 torch) re-run at different intra-op thread counts
     (torch's conv / GEMM kernels change their summation order with the thread count) vs the reference's recorded run -- the
     number of VQ codes that flip between two fp32 CPU runs of the same algorithm is the yardstick for the HIP path's flips."""
@@ -656,8 +691,10 @@ def _oracle_flip_counts(g, run, S, threads=(1, 16)):
     return res
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("run,S", [("ddim4", 4), ("ddim50", 50)])
+# (r06) the single-plane throughput mode keeps ONE end-to-end leg (ddim4): it is outside the north star's tolerance by design and
+# its DDIM-50 leg asserted the same recorded bounds a second time
+@pytest.mark.parametrize("run,S,precision", [pytest.param("ddim4", 4, "bf16x3", marks=pytest.mark.gate), ("ddim50", 50, "bf16x3"), ("ddim4", 4, "bf16")],
+                         ids=["ddim4-4-bf16x3", "ddim50-50-bf16x3", "ddim4-4-bf16"])
 def test_config1_full_width_end_to_end(run, S, precision):
     """BASELINE config 1: layout2i f8f4 at FULL width, B = 1, DDIM eta = 1, against the reference's own CPU run
     (tests/golden/make_golden.py sampler_full; noise = torch's CPU generator after manual_seed(23), like the reference).
@@ -665,7 +702,7 @@ def test_config1_full_width_end_to_end(run, S, precision):
     bounds recorded in DESIGN.md §5."""
     from frido.models.diffusion.ddim import DDIMSampler
     g = golden("sampler_full")
-    model = _frido(UNET_FULL, VQ_FULL, precision=precision)
+    model = _frido(UNET_FULL, VQ_FULL, precision=precision, shared=True)
     c = torch.from_numpy(g["c"]).cuda()
     rec = _Rec()
     torch.manual_seed(23)
@@ -705,7 +742,7 @@ E2E_X3 = dict(latent_rel=5e-5, vq_flip_rate=1e-9, pix_max=1e-4)
 E2E_BF16 = dict(latent_rel=3e-2, vq_flip_rate=4e-2, pix_p50=5e-2, pix_p99=0.6, forced_pix_max=8e-2)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3"])      # (r06) the single-plane leg went with config 1's second one, see above
 def test_config3_t2i_true_dims_plms_cfg(precision):
     """BASELINE config 3 at the real f16f8 dimensions (configs/frido/t2i/frido_f16f8_coco_clip.yaml:21-77): 8 x 32 x 32 latent,
     ONE 768-d context token, PLMS (graph-captured incl. the Heun first step) with CFG 1.5, 2 x 8192-code first stage."""
@@ -713,7 +750,7 @@ def test_config3_t2i_true_dims_plms_cfg(precision):
     from frido.models.diffusion.ddim import DDIMSampler
     from golden_cfg import UNET_F16F8, VQ_F16F8
     g = golden("sampler_t2i")
-    model = _frido(UNET_F16F8, VQ_F16F8, precision=precision)
+    model = _frido(UNET_F16F8, VQ_F16F8, precision=precision, shared=True)
     c, uc = torch.from_numpy(g["c"]).cuda(), torch.from_numpy(g["uc"]).cuda()
     if precision == "bf16x3":
         unet = model.model.diffusion_model
@@ -745,7 +782,7 @@ def test_config5_three_scale_512_forward_and_decode():
     B x N x N score tensor) against the reference's outputs."""
     from golden_cfg import UNET_512, VQ_512
     g = golden("unet_512")
-    m = _unet(UNET_512)
+    m = _unet(UNET_512, shared=True)
     x, ctx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
     for s in range(3):
         e = m(x[:, :3 * (s + 1)].contiguous(), torch.from_numpy(g[f"t_{s}"]).cuda(), context=ctx, stage=s)
@@ -755,7 +792,7 @@ def test_config5_three_scale_512_forward_and_decode():
     del m
     torch.cuda.empty_cache()
     gv = golden("vq_512")
-    v = _vq(VQ_512)
+    v = _vq(VQ_512, shared=True)
     h = torch.from_numpy(gv["h"]).cuda()
     dec, code = v.decode(h, return_code=True)
     flips = float((np.asarray(code) != gv["code"]).mean())
@@ -795,7 +832,7 @@ def test_config5_three_stage_multistep_at_true_size():
     from frido.models.diffusion.ddim import DDIMSampler
     from golden_cfg import UNET_512, VQ_512
     g = golden("sampler_512")
-    model = _frido(UNET_512, VQ_512, precision="bf16x3")
+    model = _frido(UNET_512, VQ_512, precision="bf16x3", shared=True)
     c = torch.from_numpy(g["c"]).cuda()
     rec = _Rec()
     torch.manual_seed(23)
@@ -814,7 +851,7 @@ def test_config2_step_count_ddim200_end_to_end():
     B = 1, against the reference's own CPU run (tests/golden/make_golden.py sampler_ddim200) in the parity arithmetic."""
     from frido.models.diffusion.ddim import DDIMSampler
     g = golden("sampler_ddim200")
-    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3")
+    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3", shared=True)
     c = torch.from_numpy(g["c"]).cuda()
     rec = _Rec()
     torch.manual_seed(23)
@@ -853,7 +890,7 @@ def test_vq_full_width_encode_matches_reference_golden():
     """SURVEY a16 at full width (layout2i f8f4 first stage, one 256 x 256 image) vs the reference's own encode."""
     from frido_amd.synth import seeded_normal
     g = golden("vq_full_enc")
-    m = _vq(VQ_FULL)
+    m = _vq(VQ_FULL, shared=True)
     x = torch.from_numpy(np.tanh(seeded_normal("vq_full:img", (1, 3, 256, 256))))
     enc = m.encode(x.cuda())
     ref = torch.from_numpy(g["enc"])
@@ -907,7 +944,7 @@ def test_benchmarked_batch_rows_equal_single_sample_runs(B, S, rows):
     index, so row i of the batched run must reproduce the B = 1 run with sample0 = i -- whose arithmetic the B = 1 goldens pin to
     the reference -- to the parity bound: latent <= 5e-5, ZERO code flips, decoded pixels <= 1e-4 (north star: 1e-3)."""
     from frido.models.diffusion.ddim import DDIMSampler
-    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3")
+    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3", shared=True)
     ctx = _bench_ctx(B).cuda()
     kw = dict(S=S, shape=(6, 64, 64), num_stage=2, eta=1.0, verbose=False, noise="philox", seed=1004, log_every_t=10 ** 9)
     zb, _ = DDIMSampler(model).sample(batch_size=B, conditioning=ctx, **kw)
@@ -933,41 +970,84 @@ def test_benchmarked_batch_rows_equal_single_sample_runs(B, S, rows):
         vsd = synth_sd(vq_holder(VQ_FULL), "first_stage_model.")
         keep = torch.get_num_threads()
         torch.set_num_threads(min(32, os.cpu_count() or 1))
+        from oracle.vqgan import quantize
+        sf = [float(v) for v in model.scale_factor.cpu()]
         try:
-            ref_img, ref_codes = OS.decode_first_stage(lambda zz: vq_decode(vsd, VQ_FULL, zz, return_code=True), zb.cpu(),
-                                                       [float(v) for v in model.scale_factor.cpu()], [3, 3])
+            # (r06) the VQ lookup of ALL 16 rows (cheap: the quantiser alone), the decoder's pixels for the rows the B = 1 comparison above
+            # also takes -- the decoder is per sample, so three rows of the oracle meet three different 256-row tile groups of the B = 16 launch
+            zs = OS.decode_first_stage(lambda zz: zz, zb.cpu(), sf, [3, 3])
+            ref_codes = [quantize(vsd[f"first_stage_model.ms_quantize.{i}.embedding.weight"], zs[:, 3 * i:3 * i + 3])[1].reshape(B, -1) for i in range(2)]
+            ref_img, _ = OS.decode_first_stage(lambda zz: vq_decode(vsd, VQ_FULL, zz, return_code=True), zb.cpu()[list(rows)], sf, [3, 3])
         finally:
             torch.set_num_threads(keep)
-        code_diff = int(sum((ref_codes[i].reshape(B, -1).numpy() != cb[i].reshape(B, -1)).sum() for i in range(2)))
-        pix = float((ib.cpu() - ref_img).abs().max())
-        print(f"B = 16 decode vs the oracle on the HIP latent: {code_diff} of {2 * B * 4096} codes differ, pixels max-abs {pix:.2e}")
-        _record("batch16/decode_vs_oracle", dict(codes_differing=code_diff, codes_total=2 * B * 4096, pix_max=pix))
+        code_diff = int(sum((ref_codes[i].numpy() != cb[i].reshape(B, -1)).sum() for i in range(2)))
+        pix = float((ib.cpu()[list(rows)] - ref_img).abs().max())
+        print(f"B = 16 decode vs the oracle on the HIP latent: {code_diff} of {2 * B * 4096} codes differ, pixels of rows {rows} max-abs {pix:.2e}")
+        _record("batch16/decode_vs_oracle", dict(codes_differing=code_diff, codes_total=2 * B * 4096, pix_max=pix, pixel_rows=list(rows)))
         assert code_diff == 0 and pix < E2E_X3["pix_max"]
 
 
-@pytest.mark.parametrize("B", [16, 32])
+@pytest.mark.parametrize("B", [pytest.param(16, marks=pytest.mark.gate), 32])
 def test_benchmarked_batch_forward_matches_oracle(B):
     """One denoiser forward per stage at full width and the benchmark's batch against the oracle (the CPU restatement pinned
     bit-exact to the reference): the 64^2 / 32^2 convolutions run on the tiles of the headline number here."""
     from oracle.unet import unet_forward
     from frido_amd.synth import seeded_normal
-    m = _unet(UNET_FULL)
+    m = _unet(UNET_FULL, shared=True)
     sd = synth_sd(unet_holder(UNET_FULL), "model.diffusion_model.")
     x = torch.from_numpy(seeded_normal("bench:x", (B, 6, 64, 64)))
     ctx = _bench_ctx(B)
     t = torch.tensor([(37 * i + 11) % 1000 for i in range(B)])
+    # (r06) every op of the denoiser is per sample (GroupNorm, attention, convolutions): the oracle runs the first, a middle and the last
+    # ROW of the batch (its own B = 3 forward), the HIP path the whole batch on the benchmark's tiles -- a third of the CPU time of r05's
+    # all-rows oracle leg for the same tiles under test (rows of different 256-row tiles and different workgroups)
+    rows = sorted({0, B // 2 - 1, B - 1})
     keep = torch.get_num_threads()
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     try:
         for s in ((0, 1) if B == 16 else (1,)):
             xin = x[:, :3 * (s + 1)].contiguous()
-            ref = unet_forward(sd, UNET_FULL, xin, t, ctx, s)
+            ref = unet_forward(sd, UNET_FULL, xin[rows].contiguous(), t[rows], ctx[rows].contiguous(), s)
             got = m(xin.cuda(), t.cuda(), context=ctx.cuda(), stage=s)
-            r = _rel(got, ref)
-            print(f"B = {B} full-width forward stage {s}: rel err {r:.2e}")
-            assert got.shape == ref.shape and r < 2e-4, (B, s)
+            assert got.shape == (B,) + tuple(ref.shape[1:]) and bool(torch.isfinite(got).all())
+            r = _rel(got[rows], ref)
+            print(f"B = {B} full-width forward stage {s}: rows {rows} rel err {r:.2e}")
+            assert r < 2e-4, (B, s)
     finally:
         torch.set_num_threads(keep)
+
+
+@pytest.mark.gate
+def test_deferred_splitk_reductions_of_the_benchmarked_programs_match_torch():
+    """(r06 gate) tools/verify_deferred.py as a test: the step programs of the headline workload (B = 16, both stages, the PINNED tiles) run op
+    by op; after every GroupNorm that finishes a deferred split-K reduction (builder._deferred_splitk) the reduction -- slices in order,
+    bias, timestep vector, residual -- and the normalisation are recomputed in torch fp32 from the device buffers the descriptor names.
+    This is the check that found r05's plan-time aliasing race; it costs seconds."""
+    import importlib.util
+    from frido.models.diffusion.ddim import DDIMSampler
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("verify_deferred", os.path.join(root, "tools", "verify_deferred.py"))
+    vd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vd)
+    model = _frido(UNET_FULL, VQ_FULL, precision="bf16x3", shared=True)
+    B = 16
+    z, _ = DDIMSampler(model).sample(S=4, batch_size=B, shape=(6, 64, 64), conditioning=_bench_ctx(B).cuda(), num_stage=2, eta=1.0,
+                                     verbose=False, noise="philox", seed=3, log_every_t=10 ** 9)
+    torch.cuda.synchronize()
+    rt = model.model.diffusion_model.runtime()
+    eng = next(reversed(rt._sampler_engines.values()))          # most recently used = the one just run
+    assert eng.B == B
+    sp = torch.cuda.current_stream().cuda_stream
+    worst, checked = 0.0, 0
+    for si, stg in enumerate(eng.stages):
+        eng.step.zero_()
+        w, n = vd.check_prog(stg.step, f"stage{si}.step", sp, 0, quiet=True)
+        worst, checked = max(worst, w), checked + n
+    print(f"deferred split-K reductions of the B = 16 step programs: {checked} checked, worst rel err {worst:.2e}")
+    assert bool(torch.isfinite(z).all()) and worst < 1e-4
+    from frido_amd import tune
+    if tune.cache_is_pinned_for_this_library():
+        assert checked > 0, "the pinned tile cache defers split-K reductions on the 16^2 / 8^2 planes of this workload"
 
 
 def test_decode_ignores_force_not_quantize_like_the_reference():
@@ -1036,7 +1116,7 @@ def test_other_configs_at_their_per_gpu_batch(which):
     from frido_amd.synth import seeded_normal
     if which.startswith("config3"):
         B, rows, shape, nstage, cls, S, embed = 32, (0, 31), (8, 32, 32), 2, PLMSSampler, 10, [4, 4]
-        model = _frido(UNET_F16F8, VQ_F16F8, precision="bf16x3")
+        model = _frido(UNET_F16F8, VQ_F16F8, precision="bf16x3", shared=True)
         c = torch.from_numpy(seeded_normal("b3:c", (B, 1, 768)))
         c = (c / c.norm(dim=-1, keepdim=True)).cuda()                      # encoders/modules.py:213-214: L2-normalised CLIP embedding
         uc = torch.from_numpy(seeded_normal("b3:uc", (B, 1, 768)))
@@ -1044,7 +1124,7 @@ def test_other_configs_at_their_per_gpu_batch(which):
         kw = dict(eta=0.0, unconditional_guidance_scale=1.5)
     else:
         B, rows, shape, nstage, cls, S, embed = 8, (0, 7), (9, 128, 128), 3, DDIMSampler, 2, [3, 3, 3]
-        model = _frido(UNET_512, VQ_512, precision="bf16x3")
+        model = _frido(UNET_512, VQ_512, precision="bf16x3", shared=True)
         c = torch.from_numpy(seeded_normal("b5:c", (B, 92, 640))).cuda()
         uc, kw = None, dict(eta=1.0)
     base = dict(S=S, shape=shape, num_stage=nstage, verbose=False, noise="philox", seed=77, log_every_t=10 ** 9, **kw)
@@ -1087,6 +1167,13 @@ rank, world = dist.get_rank(), dist.get_world_size()
 torch.cuda.set_device(0)                     # BOTH ranks on the one GPU of the box
 dev = torch.device("cuda", 0)
 model = build_model("bf16x3", dev)
+# (r06) a RAGGED job first -- 3 images over 2 ranks: shards of 2 and 1, the padded all-gather -- then the even one
+lo3, hi3 = shard_range(3, rank, world)
+ctx3 = torch.from_numpy(synth.seeded_normal("two:ctx", (4, 26, 640))[lo3:hi3]).to(dev)
+img3 = sample_images(model, ctx3, S=4, eta=1.0, seed=77, sample0=lo3, noise="philox", total=3, gather_dtype="uint8")
+assert img3.shape == (3, 256, 256, 3) and img3.dtype == torch.uint8
+if rank == 0:
+    np.save(%(out)r + ".ragged.npy", img3.cpu().numpy())
 total = 4
 lo, hi = shard_range(total, rank, world)
 ctx = torch.from_numpy(synth.seeded_normal("two:ctx", (total, 26, 640))[lo:hi]).to(dev)
@@ -1109,6 +1196,7 @@ print("rank", rank, "ok")
 """
 
 
+@pytest.mark.gate
 def test_two_real_hip_ranks_on_one_gpu_join_to_the_single_process_result(tmp_path):
     import subprocess
     import sys
@@ -1136,6 +1224,11 @@ def test_two_real_hip_ranks_on_one_gpu_join_to_the_single_process_result(tmp_pat
     print("two ranks vs sequential shards: per-image max |diff|", [int(dseq[i].max()) for i in range(4)],
           "share differing", [round(float((dseq[i] > 0).float().mean()), 6) for i in range(4)])
     assert torch.equal(joined, seq)
+    # (r06) the ragged job (3 images: rank 0 owns two, rank 1 one -- the zero-padded all-gather and its un-padding): image i is keyed by its
+    # GLOBAL index, so images 0-1 are the first shard above bit for bit and image 2 is a B = 1 run at sample0 = 2
+    ragged = torch.from_numpy(np.load(out_npy + ".ragged.npy"))
+    last = sample_images(model, ctx[2:3].contiguous(), sample0=2, **dict(kw, total=1)).cpu()
+    assert ragged.shape == (3, 256, 256, 3) and torch.equal(ragged[:2], seq[:2]) and torch.equal(ragged[2:], last)
     # (b) the whole batch in ONE launch sequence (B = 4 selects other tiles / wave counts than B = 2: fp32 summation orders differ): the
     # latents agree to the parity bound; the uint8 images up to truncation boundaries (and wherever an unconverged DDIM-4 latent sits
     # on a VQ decision boundary, DESIGN.md section 5 -- reported, not asserted)

@@ -30,7 +30,7 @@ def f32(ptr, shape, sp):
     return dev_copy(ptr, 4 * n, sp).view(torch.float32).view(*shape).clone()
 
 
-def check_prog(prog, name, sp, step_val):
+def check_prog(prog, name, sp, step_val, quiet=False):
     names = {v: k[len("FRIDO_OP_"):] for k, v in _lib.OP_KINDS.items()}
     worst = 0.0
     nchk = 0
@@ -80,10 +80,12 @@ def check_prog(prog, name, sp, step_val):
         nchk += 1
         worst = max(worst, err, ex)
         flag = "" if max(err, ex) < 1e-4 else "   <<<<<< MISMATCH"
+        if quiet and not flag:
+            continue
         print(f"  {name} op {i}: GN_FUSED<-sk{st.sk_n} B={B} HW={HW} C={C1}+{C2} spade={bool(st.gamma)} resid={bool(st.sk_residual)} rowvec={bool(st.sk_rowvec)} inplace={bool(st.sk_out) and st.sk_out == st.sk_residual} "
               f"x1_dead={not st.sk_out}: x1 err {ex:.2e}, out err {err:.2e}{flag}")
     print(f"{name}: {nchk} deferred reductions checked, worst {worst:.2e}")
-    return worst
+    return (worst, nchk) if quiet else worst
 
 
 def main():
