@@ -11,13 +11,26 @@ PRECISION = os.environ.get("FRIDO_PRECISION", "bf16x3")
 #           for checkpoints whose un-normalised operands leave fp16's +-65504 (the status word's FRIDO_STATUS_SATURATED says so).
 
 
+# (r06) WHICH plane format a two-plane model runs on is the library's choice, not the user's: a module whose precision is the default
+#           keyword "bf16x3" starts on the fp16 pairs (22 mantissa bits) and, when a run saturates an fp16 operand plane (the status word's
+#           FRIDO_STATUS_SATURATED, polled in stream order after every sampling pass / decode / forward), is moved to the bf16-pair build
+#           and the run is repeated there (frido_amd/autoplanes.py).  "bf16x3_f16" pins the fp16 pairs (saturation then only warns),
+#           "bf16x3_bf16" pins the bf16 pairs; FRIDO_AUTO_PLANES=0 turns the automatic move off process-wide.
+AUTO_PLANES = os.environ.get("FRIDO_AUTO_PLANES", "1") != "0"
+
+
 def nsplit(precision=None):
     p = precision or PRECISION
-    if p in ("bf16x3", "bf16x3_bf16"):
+    if p in ("bf16x3", "bf16x3_bf16", "bf16x3_f16"):
         return 2
     if p == "bf16":
         return 1
-    raise ValueError(f"unknown precision '{p}' (use 'bf16x3', 'bf16x3_bf16' or 'bf16')")
+    raise ValueError(f"unknown precision '{p}' (use 'bf16x3', 'bf16x3_f16', 'bf16x3_bf16' or 'bf16')")
+
+
+def auto_planes(precision=None):
+    """True when the plane format of a module with this precision keyword is the library's to choose (see AUTO_PLANES above)."""
+    return AUTO_PLANES and (precision or PRECISION) == "bf16x3"
 
 
 def planes(precision=None):

@@ -77,7 +77,8 @@ namespace {
 __device__ unsigned g_frido_status_word = 0;
 }
 typedef int (*frido_status_accessor)(unsigned* word, int clear);
-void frido_register_status_word(frido_status_accessor fn);       // runtime.hip
+typedef unsigned* (*frido_status_address)();                      // device address of the file's word (r06: frido_status_poll's gather kernel)
+void frido_register_status_word(frido_status_accessor fn, frido_status_address addr);       // runtime.hip
 namespace {
 inline int frido_status_rw(unsigned* word, int clear) {
     unsigned w = 0;
@@ -89,8 +90,12 @@ inline int frido_status_rw(unsigned* word, int clear) {
     *word = w;
     return FRIDO_OK;
 }
+inline unsigned* frido_status_addr() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_frido_status_word)) == hipSuccess ? (unsigned*)p : nullptr;
+}
 struct FridoStatusRegistrar {
-    FridoStatusRegistrar() { frido_register_status_word(&frido_status_rw); }
+    FridoStatusRegistrar() { frido_register_status_word(&frido_status_rw, &frido_status_addr); }
 };
 FridoStatusRegistrar g_frido_status_registrar;
 }  // namespace

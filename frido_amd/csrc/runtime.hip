@@ -315,8 +315,76 @@ std::vector<frido_status_accessor>& status_words() {
     static std::vector<frido_status_accessor> v;
     return v;
 }
+std::vector<frido_status_address>& status_addrs() {
+    static std::vector<frido_status_address> v;
+    return v;
+}
+// frido_status_poll: ONE small kernel ORs (and optionally clears) the per-file words in stream order and leaves the result where a
+// pinned host word picks it up -- one stream synchronisation instead of a device drain plus two blocking symbol copies per file
+__global__ void status_gather_kernel(unsigned* const* words, int n, unsigned* out, int clear) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned all = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned w = clear ? atomicExch(words[i], 0u) : atomicOr(words[i], 0u);
+        all |= w;
+    }
+    *out = all;
+}
+struct StatusPoll {
+    std::mutex mu;
+    unsigned** d_words = nullptr;      // device array of the per-file word addresses
+    unsigned* d_out = nullptr;
+    unsigned* h_out = nullptr;         // pinned
+    int n = 0;
+    int dev = -1;
+};
+StatusPoll g_poll;
 }  // namespace
-void frido_register_status_word(frido_status_accessor fn) { status_words().push_back(fn); }
+void frido_register_status_word(frido_status_accessor fn, frido_status_address addr) {
+    status_words().push_back(fn);
+    status_addrs().push_back(addr);
+}
+
+extern "C" int frido_status_poll(frido_stream_t stream, uint32_t* flags, int32_t clear) {
+    if (!flags) {
+        frido_set_error("frido_status_poll: null pointer");
+        return FRIDO_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_poll.mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        frido_set_error("frido_status_poll: no HIP device");
+        return FRIDO_EHIP;
+    }
+    if (g_poll.dev != dev) {           // first call (or another device): gather the word addresses of this device's copy of every file's global
+        std::vector<unsigned*> host;
+        for (auto fn : status_addrs()) {
+            unsigned* p = fn();
+            if (!p) {
+                frido_set_error("frido_status_poll: hipGetSymbolAddress failed: %s", hipGetErrorString(hipGetLastError()));
+                return FRIDO_EHIP;
+            }
+            host.push_back(p);
+        }
+        if (g_poll.d_words) { (void)hipFree(g_poll.d_words); (void)hipFree(g_poll.d_out); (void)hipHostFree(g_poll.h_out); g_poll.d_words = nullptr; }
+        if (hipMalloc((void**)&g_poll.d_words, host.size() * sizeof(unsigned*)) != hipSuccess || hipMalloc((void**)&g_poll.d_out, sizeof(unsigned)) != hipSuccess ||
+            hipHostMalloc((void**)&g_poll.h_out, sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+            hipMemcpy(g_poll.d_words, host.data(), host.size() * sizeof(unsigned*), hipMemcpyHostToDevice) != hipSuccess) {
+            frido_set_error("frido_status_poll: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+            return FRIDO_EHIP;
+        }
+        g_poll.n = (int)host.size();
+        g_poll.dev = dev;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(status_gather_kernel, dim3(1), dim3(64), 0, s, g_poll.d_words, g_poll.n, g_poll.d_out, (int)clear);
+    if (hipMemcpyAsync(g_poll.h_out, g_poll.d_out, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        frido_set_error("frido_status_poll: %s", hipGetErrorString(hipGetLastError()));
+        return FRIDO_EHIP;
+    }
+    *flags = *g_poll.h_out;
+    return FRIDO_OK;
+}
 
 // diagnostic: the word of ONE translation unit (registration = link order: igemm, convgn, norm, misc, attn, flash, runtime); -1 past the end
 extern "C" int frido_status_word_of(int32_t idx, uint32_t* word) {

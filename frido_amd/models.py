@@ -83,6 +83,9 @@ class _Versioned:
     def invalidate(self):
         self._rt = None
 
+    # which build of the library the module runs on (_lib.use_planes); the default precision keyword lets autoplanes.run() change it
+    planes = property(lambda self: config.planes(getattr(self, "precision", None)))
+
     def _apply(self, fn, *a, **k):   # .cuda() / .to() move the weights -> recompile
         self._rt = None
         return super()._apply(fn, *a, **k)
@@ -150,7 +153,8 @@ class PyUNetModel(_Versioned, nn.Module):
             _no_cpu("PyUNetModel.forward", x.device)
         if self.num_stage > 1 and not isinstance(stage, int):
             stage = int(stage)
-        return self.runtime().forward(x, timesteps, context, stage)
+        from . import autoplanes
+        return autoplanes.run(self, lambda _n: self.runtime().forward(x, timesteps, context, stage), "PyUNetModel.forward")
 
 
 UNetModel = PyUNetModel   # `ldm.modules.diffusionmodules.openaimodel.UNetModel` alias used by two shipped configs
@@ -228,7 +232,9 @@ class VQModelInterface(_Versioned, _Base):
             _no_cpu("VQModelInterface.decode", h_in.device)
         # force_not_quantize: accepted and IGNORED, exactly like the reference (msvqgan.py:376-399 never reads the flag: the
         # multi-scale decode always quantises)
-        out = self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code, to_uint8=to_uint8, force_codes=force_codes)
+        from . import autoplanes
+        out = autoplanes.run(self, lambda _n: self.runtime().decode(h_in, inv_scale=inv_scale, return_code=return_code, to_uint8=to_uint8,
+                                                                    force_codes=force_codes), "VQModelInterface.decode")
         if return_code:
             dec, idx = out
             return dec, [i.tolist() for i in idx]     # the reference's host lists (msvqgan.py:390)
@@ -240,7 +246,8 @@ class VQModelInterface(_Versioned, _Base):
         if not x.is_cuda:
             _no_cpu("VQModelInterface.encode", x.device)
         assert len(self.channel_range) != 2, "channel_range slicing is not used by any shipped config"
-        return self.runtime().encode(x, scale=scale)
+        from . import autoplanes
+        return autoplanes.run(self, lambda _n: self.runtime().encode(x, scale=scale), "VQModelInterface.encode")
 
 
 PLAN_CACHE_SIZE = 4      # compiled cond-stage plans kept per (batch, tokens) shape (like samplers.ENGINE_CACHE_SIZE)

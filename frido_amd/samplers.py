@@ -89,14 +89,20 @@ class _SamplerBase:
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         if unconditional_guidance_scale != 1.:
             assert unconditional_conditioning is not None
-        eng = self._engine(batch_size, tuple(shape), conditioning.shape[1], S, eta, unconditional_guidance_scale, num_stage,
-                           temperature, replica)
         if verbose:
             print(f"Data shape for {self.KIND.upper()} sampling is {(batch_size, *shape)}, eta {eta}")
         self.num_stage = num_stage
-        return eng.run(conditioning, unconditional_conditioning, x_T=x_T, noise=noise, seed=seed, sample0=sample0,
-                       log_every_t=log_every_t, callback=callback, img_callback=img_callback, noise_dropout=noise_dropout,
-                       score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, model=self.model)
+
+        def go(noise_src):
+            # the engine is looked up per attempt: a repeated run (autoplanes: the default plane format saturated) belongs to the
+            # denoiser's NEW runtime on the bf16-pair build, with its own plans, buffers and graphs
+            eng = self._engine(batch_size, tuple(shape), conditioning.shape[1], S, eta, unconditional_guidance_scale, num_stage,
+                               temperature, replica)
+            return eng.run(conditioning, unconditional_conditioning, x_T=x_T, noise=noise_src, seed=seed, sample0=sample0,
+                           log_every_t=log_every_t, callback=callback, img_callback=img_callback, noise_dropout=noise_dropout,
+                           score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, model=self.model)
+        from . import autoplanes
+        return autoplanes.run(self.model.model.diffusion_model, go, f"{type(self).__name__}.sample", noise=noise)
 
 
 class DDIMSampler(_SamplerBase):

@@ -40,7 +40,7 @@ typedef uint16_t frido_bf16;
  * GroupNorm-apply input gn_*), two-plane operand producers saturate at +-65504.  4 (r04): FridoGemm.sk_mode 2 + FridoGnApply.sk_* at the
  * struct's END (a split-K GEMM's reduction finished by the GroupNorm launch that consumes its output).  5 (r05): FridoAttnSmall.skip_act_store
  * at the struct's END; frido_status_flags(&word, clear) (sticky saturation / non-finite flags; clear = 1 resets them). */
-#define FRIDO_ABI_VERSION 5
+#define FRIDO_ABI_VERSION 6
 #define FRIDO_SPLITK_HEADER_BYTES 65536     /* the ticket header at the start of a split-K workspace; partial sums follow: [splitk][M][N] f32 */
 
 #define FRIDO_OK 0
@@ -475,6 +475,11 @@ const char* frido_last_error(void);
 #define FRIDO_STATUS_SATURATED 1u
 #define FRIDO_STATUS_NONFINITE 2u
 int frido_status_flags(uint32_t* flags, int32_t clear);
+/* (r06, ABI 6) The same word in STREAM ORDER: one small kernel on `stream` ORs (clear != 0: and resets) the per-file words, the result
+ * comes back through a pinned host word after ONE hipStreamSynchronize(stream) -- no device drain, no blocking symbol copies.  This is
+ * what the host side calls after a sampling pass / a decode to decide whether the model must move to the bf16-pair planes
+ * (frido_amd/models.py auto plane selection); not capturable (it synchronises the stream). */
+int frido_status_poll(frido_stream_t stream, uint32_t* flags, int32_t clear);
 /* diagnostic: the status word of ONE source file of the library (index = link order: igemm, convgn, norm, misc, attn, flash, runtime);
  * returns -1 past the last one.  tools/find_saturation.py uses it to name the kernel family that raised a bit. */
 int frido_status_word_of(int32_t idx, uint32_t* word);

@@ -361,3 +361,63 @@ def test_plane_format_selection_and_pool_hold_host_logic():
     assert held is a and pool.alloc(1000) is not a          # while held, the same size class hands out a fresh buffer
     pool.release(held)
     assert pool.alloc(1000) is a
+
+
+def test_auto_plane_selection_host_logic(monkeypatch):
+    """r06 (frido_amd/autoplanes.py) without a GPU: a module on the DEFAULT precision keyword whose run saturates an fp16 plane is moved to
+    the bf16-pair build and the call repeated with the host noise REWOUND (torch's generator state, a recorded tape); the discarded
+    attempt's SATURATED bit does not reach the sticky word, other bits do; pinned keywords and FRIDO_AUTO_PLANES=0 run once."""
+    import types
+    import warnings
+    from frido_amd import _lib, autoplanes, config
+
+    class M:
+        def __init__(self, precision=None):
+            self.precision, self.invalidated = precision, 0
+        planes = property(lambda self: config.planes(self.precision))
+
+        def invalidate(self):
+            self.invalidated += 1
+
+    script, polled = [], []
+
+    def fake_poll(planes=None, clear=True, keep=True):
+        polled.append(planes)
+        w = script.pop(0)
+        if clear and keep:
+            _lib._sticky[0] |= w
+        return w
+    monkeypatch.setattr(_lib, "status_poll", fake_poll)
+    monkeypatch.setattr(_lib, "lib", lambda planes=None: types.SimpleNamespace(frido_status_poll=True))
+    monkeypatch.setattr(_lib, "_sticky", [0])
+    assert config.auto_planes(None) and config.auto_planes("bf16x3") and not config.auto_planes("bf16x3_f16") and not config.auto_planes("bf16x3_bf16")
+    assert (config.nsplit("bf16x3_f16"), config.planes("bf16x3_f16")) == (2, "f16")
+    # (1) clean run: one call; an earlier bit and a NONFINITE bit of the run both stay visible
+    m, calls = M(), []
+    script[:] = [_lib.STATUS_NONFINITE, 0]
+    assert autoplanes.run(m, lambda n: calls.append(n) or "out", "t", noise="philox") == "out"
+    assert calls == ["philox"] and m.precision is None and _lib._sticky[0] == _lib.STATUS_NONFINITE and not script
+    # (2) saturated run: repeated on the bf16 pairs with the SAME host noise (generator and tape), one warning, SATURATED not kept
+    _lib._sticky[0] = 0
+    m, draws = M("bf16x3"), []
+    tape = iter([torch.full((2,), 1.0), torch.full((2,), 2.0), torch.full((2,), 99.0)])
+    script[:] = [0, _lib.STATUS_SATURATED | _lib.STATUS_NONFINITE, 0]
+
+    def call(noise):
+        draws.append((torch.randn(3), noise((2,)).clone(), noise((2,)).clone(), m.planes))
+        return len(draws)
+    torch.manual_seed(5)
+    with pytest.warns(_lib.FridoNumericsWarning, match="bf16-pair planes"):
+        assert autoplanes.run(m, call, "t", noise=lambda shape: next(tape)) == 2
+    assert m.precision == "bf16x3_bf16" and m.planes == "bf16" and m.invalidated == 1 and polled[-3:] == ["f16", "f16", "bf16"]
+    assert draws[0][3] == "f16" and draws[1][3] == "bf16"
+    assert all(torch.equal(draws[0][i], draws[1][i]) for i in range(3)) and float(draws[1][2][0]) == 2.0      # rewound, not re-drawn
+    assert _lib._sticky[0] == _lib.STATUS_NONFINITE
+    # (3) pinned formats / the switch off: exactly one call, no polls
+    for mod, auto in ((M("bf16x3_f16"), True), (M("bf16x3_bf16"), True), (M("bf16"), True), (M(), False)):
+        monkeypatch.setattr(config, "AUTO_PLANES", auto)
+        n0, script[:] = len(polled), []
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            assert autoplanes.run(mod, lambda n: "x", "t") == "x"
+        assert len(polled) == n0 and mod.invalidated == 0
