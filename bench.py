@@ -46,6 +46,34 @@ def build_model(precision, device):
     return m.to(device).eval()
 
 
+def family_gflop_per_forward(eng):
+    """Algorithmic 2MNK of the GEMM-family launches of ONE denoiser forward, per stage (GFLOP)."""
+    from frido_amd import _lib
+    k_gemm = _lib.OP_KINDS["FRIDO_OP_GEMM"]
+    return [sum(2.0 * st.M * st.N * (st.K + st.K2) * st.batch for kind, st in stg.step.ops if kind == k_gemm) / 1e9 for stg in eng.stages]
+
+
+def trace_roofline(gflop_per_stage, peak):
+    """(r06, r05 verdict next 7) The family's figure from the REPLAYED graph: the committed kernel trace of this bench command
+    (tools/run_profiles.sh -> tools/gap_analysis.py `sampling_loop`: summed durations of the family's kernels between the first and the
+    last update kernel of one sampling pass, and the number of forwards in that window) against this run's algorithmic FLOPs per
+    forward.  Not measured in this process: named by its source file."""
+    for tag in ("r06_x3", "r05_x3"):
+        path = os.path.join(REPO, "profiles", f"{tag}_gap_analysis.json")
+        if not os.path.exists(path):
+            continue
+        loop = json.load(open(path)).get("sampling_loop") or {}
+        if not loop.get("gemm_family_ms_per_forward"):
+            continue
+        g = sum(gflop_per_stage) / len(gflop_per_stage)
+        ach = g / loop["gemm_family_ms_per_forward"]                 # GFLOP / ms = TFLOP/s
+        return {"source": f"profiles/{tag}_gap_analysis.json (rocprofv3 --kernel-trace of `bench.py --steps 1 --warmup 1`, one sampling pass)",
+                "forwards_in_window": loop["forwards"], "gemm_family_ms_per_forward": round(loop["gemm_family_ms_per_forward"], 4),
+                "forward_ms_wall": round(loop["forward_ms_wall"], 4), "alg_gflop_per_forward": round(g, 2),
+                "achieved": round(ach, 2), "frac": round(ach / peak, 4), "unit": "TFLOP/s"}
+    return None
+
+
 def gemm_roofline(eng, stream_ptr, precision):
     """Per-op HIP-event timing of one stage-1 denoiser forward; aggregates the MFMA implicit-GEMM launches."""
     from frido_amd import _lib
@@ -84,9 +112,9 @@ def gemm_roofline(eng, stream_ptr, precision):
     peak = 2500.0
     two_plane_f16 = precision == "bf16x3" and _lib.lib().frido_x3_plane_format() == 1
     insn = "v_mfma_f32_16x16x32_f16" if two_plane_f16 else "v_mfma_f32_16x16x32_bf16"
-    tag = "r05_x3" if precision == "bf16x3" else "r02"
+    tag = "r06_x3" if precision == "bf16x3" else "r02"
     prof = {}
-    for t in (tag, "r04_x3", "r03_x3"):
+    for t in (tag, "r05_x3", "r04_x3", "r03_x3"):
         pmc = os.path.join(REPO, "profiles", f"{t}_pmc_traffic.json")
         if os.path.exists(pmc):  # HBM bytes per launch from a COMMITTED rocprofv3 --pmc pass (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run
             blob = json.load(open(pmc))
@@ -96,14 +124,14 @@ def gemm_roofline(eng, stream_ptr, precision):
                 prof["traffic_source"] = (f"profiles/{t}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, reads x2; "
                                           "launch-weighted mean over the family)")
             break
-    for t in (tag, "r04_x3", "r03_x3"):
+    for t in (tag, "r05_x3", "r04_x3", "r03_x3"):
         pm = os.path.join(REPO, "profiles", f"{t}_pmc_mfma.json")
         if os.path.exists(pm):   # matrix-pipe busy share of the family's kernels (SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_sq.py)
             blob = json.load(open(pm))
             prof["mfma_busy_pmc"] = {k: blob[k].get("mfma_busy_frac") for k in GEMM_FAMILY if k in blob}
             prof["mfma_busy_source"] = f"profiles/{t}_pmc_mfma.json"
             break
-    for t in (tag, "r04_x3", "r03_x3"):
+    for t in (tag, "r05_x3", "r04_x3", "r03_x3"):
         csv_p = os.path.join(REPO, "profiles", f"{t}_bench_kernel_stats.csv")
         if os.path.exists(csv_p):    # the same family in the committed rocprofv3 --kernel-trace --stats summary of the bench command
             import csv
@@ -530,6 +558,13 @@ def main():
             eng.step.zero_()
             stg.step.run(sp)
             ev_ms.append(float(sum(stg.step.run_timed(sp))))
+        gfl = family_gflop_per_forward(eng)
+        roof["alg_gflop_per_forward_by_stage"] = [round(g, 2) for g in gfl]
+        # `forward_ms` of this block = the forward as the sampler RUNS it (loop-only pass / forwards: graph replays); the per-op event sum it
+        # used to hold is `forward_ms_events` (eager, every op bracketed by events: longer) -- forward_ms x forwards <= ms_per_step holds
+        roof["forward_ms_events"] = roof["forward_ms"]
+        roof["forward_ms"] = round(fwd_graph_ms, 3)
+        roof["trace"] = trace_roofline(gfl, roof["peak"])
         if ev_ms and fwd_graph_ms > 0:
             # ratio only: small launches carry most of the event overhead, so scaling the GEMM figure by it would flatter it
             roof["event_vs_graph"] = {"forward_ms_replayed": round(fwd_graph_ms, 3), "forward_ms_events": [round(t, 3) for t in ev_ms],
@@ -580,7 +615,7 @@ def main():
             d1 = (time.perf_counter() - t0) / args.steps
             extra = {"dtype": "bf16", "value": round(total / d1, 4), "unit": "images/s", "ms_per_step": round(1e3 * d1, 2),
                      "steps": args.steps, "meets_1e-3_tolerance": False}
-            for name in ("r05_e2e_error.json", "r04_e2e_error.json", "r03_e2e_error.json"):
+            for name in ("r06_e2e_error.json", "r05_e2e_error.json", "r04_e2e_error.json", "r03_e2e_error.json"):
                 e2e = os.path.join(REPO, "profiles", name)
                 if os.path.exists(e2e):         # end-to-end error of both arithmetic modes vs the reference's own CPU run (GPU tests write it)
                     extra["e2e_error_vs_reference"] = {"from_committed_profile": f"profiles/{name}", "record": json.load(open(e2e))}

@@ -55,12 +55,17 @@ namespace {
 __device__ uint4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 
 // (LDS / waitcnt helpers, xcd_item, static_for, chan_of_pos, tile_epilogue: igemm_shared.h)
-template <int BM, int BN, int NS, int BK, bool W8 = false>
+// KG = 2 (r06, "intra-workgroup split-K", tiles 31 / 33 / 34 / 35 / 36): TWO 4-wave groups in one 8-wave workgroup, group g running the
+// unmodified 4-wave loop over k-tiles [g * nk / 2, (g + 1) * nk / 2) on its own ring; group 1 hands its accumulators to group 0 through
+// LDS and exits, group 0 adds them (acc0 + acc1: one fixed order) and runs the epilogue.  For the SUB-ROUND dense launches of the 8^2 / 16^2
+// planes (160 - 320 workgroups of 64 x 64 ... 128 x 128 tiles: ONE wave per SIMD, every k-tile one exposed L2 -> LDS round trip): two
+// waves per SIMD and half the k-steps per wave, with no second launch, no workspace and no agent-scope hand-off.
+template <int BM, int BN, int NS, int BK, bool W8 = false, int KG = 1>
 struct Geo {
     // waves along M (x 2 along N): 4 or 8 waves per workgroup.  W8 (r03, tile 18 = 128 x 192): EIGHT waves on a 128-row tile, wave
     // tile 32 x 96 -- one workgroup of 8 waves per CU where 128 x 192 tiles give exactly 256 or 512 workgroups
     static constexpr int WMW = (BM >= 256 || W8) ? 4 : 2;
-    static constexpr int NW = WMW * 2, NT = NW * 64;
+    static constexpr int NW = WMW * 2, NT = NW * 64 * KG;      // NW: waves of ONE k-group (the DMA dealing and the wave grid are per group)
     static constexpr int ROWB = BK * 2;                     // bytes per LDS row
     static constexpr int CHR = 1024 / ROWB;                 // rows per 1-KiB LDS-DMA chunk (16 / 8)
     // 1-KiB chunks per wave per plane.  The weight panel may deal UNEVENLY: with JBR != 0 only waves 0 .. JBR - 1 carry chunk JB - 1
@@ -84,7 +89,10 @@ struct Geo {
     // + the bf16 residual sub-tile of every wave, DMA'd into the idle ring at the start of the epilogue (bf16 mode)
     static constexpr bool RSTAGE = NS == 1 && SLABS + BM * BN * 2 <= 163840;
     static constexpr int EPI = SLABS + (RSTAGE ? BM * BN * 2 : 0);
-    static constexpr int SMEM = D * STAGE > EPI ? D * STAGE : EPI;
+    static constexpr int RED_OFF = (EPI + 15) / 16 * 16;      // KG = 2: group 1's accumulators are parked BEHIND the epilogue's slabs
+    static constexpr int EPI_ALL = KG == 2 ? RED_OFF + BM * BN * 4 : EPI;
+    static constexpr int SMEM = KG * D * STAGE > EPI_ALL ? KG * D * STAGE : EPI_ALL;
+    static_assert(KG == 1 || (KG == 2 && NS == 2 && BK == 32 && !W8 && BM < 256), "k-groups: 4-wave two-plane tiles only");
     static_assert(SMEM <= 163840, "LDS budget");
 };
 
@@ -99,9 +107,9 @@ __device__ __forceinline__ void wait_tail(int rem) {
     }
 }
 
-template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false>
-__global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK, W8>::NW == 8 ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
-    using G = Geo<BM, BN, NS, BK, W8>;
+template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false, int KG = 1>
+__global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS, BK, W8, KG>::NW == 8 || KG == 2) ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
+    using G = Geo<BM, BN, NS, BK, W8, KG>;
     constexpr int JBR = G::JBR;
     constexpr int ROWB = G::ROWB, CHR = G::CHR, KS = BK / 32;
     constexpr int WM = G::WMW, WN = 2, NW = G::NW;
@@ -111,8 +119,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave_wg = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kg = KG == 2 ? wave_wg >> 2 : 0;                 // k-group of this wave (KG = 2: waves 0..3 / 4..7)
+    const int wave = KG == 2 ? wave_wg & 3 : wave_wg;          // wave within its group: DMA dealing, wave grid, epilogue slabs
     const int wm = wave >> 1, wn = wave & 1;
+    unsigned char* const ring = smem + kg * (D * STAGE);       // this group's LDS ring
 
     // ---- block -> tile (XCD-aware: consecutive logical tiles share an A row-panel and an XCD L2) ----
     const int tiles_n = (d.N + BN - 1) / BN;
@@ -123,7 +134,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     // split-K an XCD works on ONE k-slice (or a few), so its L2 holds that slice of the weights once.  Before (k-slice =
     // blockIdx.z, every XCD walked all slices): the 8x8-plane convs (M = 1024, split 8) fetched 72 MB per launch from
     // MALL / HBM for 18.6 MB of operands (tools/_pmc_smallm.sh).
-    const int kz = xcd_item(nb) / nb;
+    const int kz = xcd_item(nb) / nb;                          // (KG = 2 launches have gridDim.z == 1: kz = 0)
     const int bid = xcd_item(nb) - kz * nb;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -209,8 +220,10 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
 
     // k-tile range of this workgroup (split-K: gridDim.z slices)
     const int nk_all = (d.K + d.K2) / BK;
-    const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int kt0 = kz * per;
+    // (KG = 2: the two groups of the workgroup are the two "slices"; the launcher admits an even number of k-tiles only, so both
+    //  groups run the same number of loop iterations and meet at the same workgroup-wide barriers)
+    const int per = KG == 2 ? nk_all / 2 : (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = (KG == 2 ? kg : kz) * per;
     const int nk = max(0, min(nk_all, kt0 + per) - kt0);
     const int cin = d.Cin, kw = d.kw, ws = d.Ws;
     // keep the zero page's address in SGPRs (otherwise hipcc re-loads it from the GOT inside the k-loop)
@@ -294,7 +307,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     auto issue_begin = [&]() { if (seg_left == 0) retap(); };
     auto issue_piece = [&](auto pc, int buf) {
         constexpr int pi = decltype(pc)::value;
-        unsigned char* sb = smem + buf * STAGE + wave * 1024;
+        unsigned char* sb = ring + buf * STAGE + wave * 1024;
         if constexpr (pi < JA) {
             __builtin_amdgcn_global_load_lds((gptr_t)aptr[pi], (lptr_t)(sb + pi * (NW * 1024)), 16, 0, 0);
             aptr[pi] += astep[pi];
@@ -308,7 +321,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     auto issue_end = [&]() { advance(); };
     auto issue = [&](int buf) {
         if (seg_left == 0) retap();
-        unsigned char* sb = smem + buf * STAGE + wave * 1024;
+        unsigned char* sb = ring + buf * STAGE + wave * 1024;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
             __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(sb + j * (NW * 1024)), 16, 0, 0);
@@ -340,7 +353,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     const int frow = lane & 15;
     const int fslot0 = BK == 32 ? ((lane >> 4) ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4 : ((lane >> 4) ^ (frow >> 1)) << 4;
     const int fslot1 = ((4 + (lane >> 4)) ^ (frow >> 1)) << 4;          // second k-step of a BK = 64 row
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)ring;
     const unsigned a_frag = lds0 + (wm * (BM / WM) + frow) * ROWB;
     const unsigned b_frag = lds0 + BM * ROWB + (wn * (BN / WN) + frow) * ROWB;
 
@@ -497,7 +510,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
         // DMA piece pi of the refill in progress: (A chunk 0 hi, lo), (A chunk 1 hi, lo), ..., (B chunk 0 hi, lo), ...
         auto piece = [&](auto pc) {
             constexpr int pi = decltype(pc)::value, idx = pi >> 1, pl = pi & 1;
-            unsigned char* sb = smem + dbuf * STAGE + pl * PLANE + wave * 1024;
+            unsigned char* sb = ring + dbuf * STAGE + pl * PLANE + wave * 1024;
             if constexpr (idx < JA) {
                 const frido_bf16* src = (pl && astep[idx]) ? aptr[idx] + alo_cur : aptr[idx];
                 if constexpr (FRIDO_ABLATE & 32) src = reinterpret_cast<const frido_bf16*>(zero_addr) + (lane & 3) * 8;   // same 64 bytes for every piece
@@ -667,7 +680,27 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8>::NT), (Geo<BM, BN, NS, BK,
     //      fragment-major (16 coalesced bytes per lane and fragment); the LAST workgroup of the tile to arrive adds all slices in
     //      slice order -- the sum does not depend on who is last -- and runs the normal epilogue.  Nobody waits for anybody.
     bool reduced = false;
-    if (gridDim.z > 1 && d.sk_mode == 1) {
+    if constexpr (KG == 2) {
+        // ---- the two k-groups' partial tiles -> one: group 1 parks its accumulators (fragment-major: 16 contiguous bytes per lane and
+        //      fragment, conflict-free) behind the epilogue's slab area and EXITS; group 0 adds them -- always acc0 + acc1 -- and goes
+        //      on alone.  (s_barrier waits for the SURVIVING waves of a workgroup only, so the epilogue's own barriers stay valid.)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // both groups are done with their rings (the park area overlaps them)
+        float* red = reinterpret_cast<float*>(smem + G::RED_OFF) + (t & 255) * 4;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(red + (i * TN + j) * 1024) = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(red + (i * TN + j) * 1024);
+    }
+    if (KG == 1 && gridDim.z > 1 && d.sk_mode == 1) {
         constexpr int NT = G::NT, SLAB = BM * BN;
         const int S = (int)gridDim.z;
         float* part = d.ws + SK_HDR + (int64_t)bid * S * SLAB;
@@ -1344,10 +1377,10 @@ void launch_splitk_reduce(const FridoGemm& d, hipStream_t s) {
     else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, d);
 }
 
-template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false>
+template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false, int KG = 1>
 int set_attr() {
-    constexpr int smem = Geo<BM, BN, NS, BK, W8>::SMEM;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV, BK, W8>),
+    constexpr int smem = Geo<BM, BN, NS, BK, W8, KG>::SMEM;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NS, CONV, BK, W8, KG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         frido_set_error("igemm: cannot set dynamic LDS size %d", smem);
         return FRIDO_EHIP;
@@ -1376,6 +1409,26 @@ int launch(const FridoGemm& d, hipStream_t s) {
         launch_splitk_reduce(dd, s);
     }
     return frido_check_launch("igemm");
+}
+
+// tiles 31 / 33 / 34 / 35 / 36 (r06): the 4-wave tile (id - 30) with K split over the two wave groups of an 8-wave workgroup (Geo, KG = 2)
+bool kg2_ok(const FridoGemm& d) {
+    const int nk = (d.K + d.K2) / 32;
+    return d.nsplit == 2 && !d.conv && d.splitk <= 1 && nk >= 2 && (nk & 1) == 0 && !d.gn_x1;
+}
+
+template <int BM, int BN>
+int launch_kg2(const FridoGemm& d, hipStream_t s) {
+    if (!kg2_ok(d)) {
+        frido_set_error("igemm: tiles 31..36 (K split inside the workgroup) take dense two-plane GEMMs with an EVEN number of 32-deep k-tiles and no split-K");
+        return FRIDO_EINVAL;
+    }
+    using G = Geo<BM, BN, 2, 32, false, 2>;
+    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    FridoGemm dd = d;
+    dd.sk_mode = 0;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, false, 32, false, 2>), dim3(tiles, d.batch, 1), dim3(G::NT), G::SMEM, s, dd);
+    return frido_check_launch("igemm (k-groups)");
 }
 
 // eligibility of the patch-staged 3x3 kernel (tile id 9)
@@ -1441,6 +1494,20 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
         if (tile == 10) return launch_patch(d, 4, s);
     }
     if (tile == 7) return launch<256, 128, NS, CONV, 32>(d, s);      // 8-wave tiles: half the L2->LDS bytes per FLOP of the 128-row tiles
+    if constexpr (NS == 2 && !CONV) {
+        switch (tile) {
+            case 31: return launch_kg2<128, 128>(d, s);
+            case 33: return launch_kg2<64, 64>(d, s);
+            case 34: return launch_kg2<128, 64>(d, s);
+            case 35: return launch_kg2<64, 192>(d, s);
+            case 36: return launch_kg2<64, 128>(d, s);
+            default: break;
+        }
+    }
+    if (tile >= 31 && tile <= 36) {
+        frido_set_error("igemm: tiles 31..36 (K split inside the workgroup) exist for dense two-plane GEMMs only");
+        return FRIDO_EINVAL;
+    }
     if constexpr (NS == 2) {
         if (tile == 18) return launch<128, 192, NS, CONV, 32, true>(d, s);     // 128 x 192 on eight waves (bf16x3)
         if (tile == 19) return launch<256, 192, NS, CONV, 32>(d, s);           // 256 x 192 on eight waves, wave tile 64 x 96 (bf16x3)
@@ -1486,6 +1553,8 @@ int frido_igemm_init() {
     FRIDO_SET_ALL(128, 64); FRIDO_SET_ALL(64, 192); FRIDO_SET_ALL(64, 128);
 #undef FRIDO_SET_ALL
     rc |= set_attr<256, 128, 2, true, 32>() | set_attr<256, 128, 2, false, 32>();
+    rc |= set_attr<128, 128, 2, false, 32, false, 2>() | set_attr<64, 64, 2, false, 32, false, 2>() | set_attr<128, 64, 2, false, 32, false, 2>() |
+          set_attr<64, 192, 2, false, 32, false, 2>() | set_attr<64, 128, 2, false, 32, false, 2>();      // K split inside the workgroup (tiles 31..36)
     rc |= set_attr<128, 192, 2, true, 32, true>() | set_attr<128, 192, 2, false, 32, true>();
     rc |= set_attr<256, 192, 2, true, 32>() | set_attr<256, 192, 2, false, 32>();
     rc |= set_attr<256, 128, 1, true, 32>() | set_attr<256, 128, 1, false, 32>() | set_attr<256, 256, 1, true, 32>() |

@@ -33,6 +33,10 @@ CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
 # benchmark's pinned tiles, every other shape a deterministic one, so a run of the suite is bitwise repeatable on any box
 ON_MISS = os.environ.get("FRIDO_TUNE_ON_MISS", "tune")
 _dirty = False
+KG2 = os.environ.get("FRIDO_TUNE_KG2", "1") != "0"
+TILES_KG2 = (31, 33, 34, 35, 36)
+KG2_DIMS = {31: (128, 128), 33: (64, 64), 34: (128, 64), 35: (64, 192), 36: (64, 128)}
+KG2_MAX_WG = int(os.environ.get("FRIDO_TUNE_KG2_MAX_WG", "640"))
 
 
 def _lib_tag():
@@ -203,9 +207,14 @@ def best_tile(st, device, stream):
         patch = (st.conv and st.nsplit == 1 and st.batch == 1 and st.kh == 3 and st.stride == 1 and not (st.up_shift or st.dn_shift)
                  and not st.up2_phase and st.M % 128 == 0 and st.M >= 4096 and st.N >= 96 and sk <= (st.Cin + st.K2) // 32)
         big_tiles = (TILES8W if st.nsplit == 1 else ((7, 18, 19) if T19 else (7, 18))) if big else ()  # bf16x3: 256 x 128 and the 8-wave 128 x 192 / 256 x 192
-        for tile in TILES + (TILES64 if k64 else ()) + big_tiles + ((17,) if big and k64 else ()) + ((9, 10) if patch else ()):
+        # (r06) tiles 31 / 33 / 34 / 35 / 36: K split over the two wave groups of ONE 8-wave workgroup (igemm.hip Geo, KG = 2) -- for dense
+        # two-plane launches that leave the chip under-filled (an even number of k-tiles, no split-K); the library rejects the rest
+        kg2 = TILES_KG2 if (KG2 and st.nsplit == 2 and not st.conv and sk == 1 and nk >= 2 and nk % 2 == 0 and not st.gn_x1) else ()
+        for tile in TILES + (TILES64 if k64 else ()) + big_tiles + ((17,) if big and k64 else ()) + ((9, 10) if patch else ()) + kg2:
             if tile % 10 in (1, 2, 4) and st.M < 64:
                 continue
+            if tile > 30 and -(-st.M // KG2_DIMS[tile][0]) * -(-st.N // KG2_DIMS[tile][1]) * st.batch > KG2_MAX_WG:
+                continue        # one 8-wave workgroup per CU: beyond ~two rounds the two-per-CU 4-wave form of the same tile wins
             t.tile = tile
             if nrot > 1:
                 ops = []

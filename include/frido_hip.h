@@ -126,7 +126,10 @@ typedef struct FridoGemm {
                                    7 = 256x128 (8 waves), 8 = 256x256 (8 waves, bf16 mode);
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64), 17 = 256x128 with BK 64;
                                    18 = 128x192 on eight waves, 19 = 256x192 on eight waves (bf16x3 mode);
-                                   20 = 256x192 / 21 = 128x192 with the GroupNorm-apply fused in (gn_* below, bf16x3 mode) */
+                                   20 = 256x192 / 21 = 128x192 with the GroupNorm-apply fused in (gn_* below, bf16x3 mode);
+                                   31 / 33 / 34 / 35 / 36 (r06) = tiles 1 / 3 / 4 / 5 / 6 with K split over the TWO wave groups of one 8-wave
+                                   workgroup (partial tiles added through LDS, acc0 + acc1): dense bf16x3 GEMMs with an even number of
+                                   32-deep k-tiles and splitk <= 1 -- for launches of fewer workgroups than the chip has CU slots */
     int32_t flags;              /* A/B switches (0 = defaults): bit 0 = do not stage the bf16 residual tile through LDS in the
                                    epilogue, bit 1 = do not hoist a launch-wide timestep vector into the bias, bit 4 = do not take the
                                    streamlined epilogues (bit 5 / 6: only the split-K / GEGLU one); TIMING EXPERIMENTS ONLY

@@ -606,6 +606,59 @@ def test_gemm_direct_epilogue_every_tile(nsplit, out, tile):
     assert _relerr(got, ref) < _tol(nsplit)
 
 
+@pytest.mark.gate
+@pytest.mark.parametrize("K", [64, 128, 320, 960])
+@pytest.mark.parametrize("tile", [31, 33, 34, 35, 36])
+def test_gemm_k_split_inside_the_workgroup(tile, K):
+    """(r06) tiles 31 / 33 / 34 / 35 / 36 = the 4-wave tiles 1 / 3 / 4 / 5 / 6 with K split over the two wave groups of an 8-wave workgroup
+    (igemm.hip Geo, KG = 2): each group runs the 4-wave loop over half the k-tiles on its own LDS ring, group 1 parks its accumulators in
+    LDS, group 0 adds them and runs the epilogue.  K = 64 / 128 / 320 / 960: 1, 2, 5 and 15 k-tiles per group (prologue only, no refill,
+    odd stage parity + wrap-around, the U-Net's shape); ragged M / N, both outputs; bit-identical on a repeat; batched per-sample
+    products; an odd number of k-tiles, a split-K request and a one-plane operand are REJECTED."""
+    from frido_amd._lib import FridoHipError
+    M, N = 300, 352
+    a, w, bias, res = _t("ka", M, K), _t("kw", N, K) / np.sqrt(K), _t("kb", N), _t("kr", M, N)
+    outs = []
+    for out in ("f32", "op", "f32"):
+        b = _builder(2, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+        ad = a.cuda()
+        a_op = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+        kw = {}
+        if out == "f32":
+            r = b.f32(M, N)
+            r.view().copy_(res.cuda())
+            kw["residual"] = r
+        o = b.linear(a_op, "w", alpha=0.75, out=out, **kw)
+        b.prog.ops[-1][1].tile = tile
+        _run(b)
+        ref = 0.75 * (a @ w.t()) + bias + (res if out == "f32" else 0)
+        got = o.view().float().cpu() if out == "f32" else o.to_f32().cpu()[:, :N]
+        assert _relerr(got, ref) < _tol(2), (tile, K, out)
+        outs.append(got)
+    assert torch.equal(outs[0], outs[2])                    # acc0 + acc1 in one fixed order: repeatable bit for bit
+    # per-sample products (batch = 5, the V^T form: the weight is the "A" side with a_bs = 0)
+    Bz, Nk, C = 5, 64, K
+    x, wv = _t("kx", Bz * Nk, C), _t("kv", 192, C) / np.sqrt(C)
+    b = _builder(2, {})
+    from frido_amd.engine import pack_matrix
+    xd = x.cuda()
+    x_op = b.pack(xd.data_ptr(), 1, Bz * Nk, C, 0, C)
+    vT = b.v_transposed(x_op, C, pack_matrix(wv.cuda().double(), 2), Bz, Nk, 192)
+    b.prog.ops[-1][1].tile = tile
+    _run(b)
+    refv = torch.einsum("dc,znc->zdn", wv, x.view(Bz, Nk, C))
+    assert _relerr(vT.to_f32().cpu().view(Bz, 192, -1)[:, :, :Nk], refv) < _tol(2)
+    # rejected forms
+    for bad_k, nsplit in ((96, 2), (K, 1)):
+        w2 = _t("kw2", N, bad_k)
+        b = _builder(nsplit, {"w.weight": w2.cuda(), "w.bias": bias.cuda()})
+        a2 = _t("ka2", M, bad_k).cuda()
+        o = b.linear(b.pack(a2.data_ptr(), 1, M, bad_k, 0, bad_k), "w", out="op")
+        b.prog.ops[-1][1].tile = tile
+        with pytest.raises(FridoHipError):
+            _run(b)
+
+
 @pytest.mark.parametrize("K", [64, 128, 192, 448])
 @pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 16, 17])
 def test_pipelined_loop_short_k(tile, K):

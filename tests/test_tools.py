@@ -125,3 +125,35 @@ def test_trace_diff_groups_by_kernel_and_grid(tmp_path, capsys):
     td.main()
     out = capsys.readouterr().out
     assert "-0.06" in out and "2048" in out
+
+
+def test_gap_analysis_sampling_loop_window(tmp_path):
+    """(r06) tools/gap_analysis.py `sampling_loop`: the kernels between the first and the last update kernel of one pass, the forwards in
+    that window and the GEMM family's summed duration per forward -- what bench.py's `roofline.trace` divides its FLOPs by."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    rows, t = [], [0]
+
+    def k(name, dur):
+        rows.append(dict(Start_Timestamp=t[0], End_Timestamp=t[0] + dur, Kernel_Name=name))
+        t[0] += dur + 100
+    k("randn_kernel", 1000)
+    k("void (anonymous namespace)::igemm_kernel<128, 128, 2, true, 32, false, 1>(FridoGemm)", 70000)          # hoisted pre-pass: outside the window
+    for _ in range(5):
+        k("void (anonymous namespace)::igemm_kernel<128, 128, 2, false, 32, false, 1>(FridoGemm)", 50000)
+        k("void (anonymous namespace)::conv3x3_gn_kernel<256, false, false>(FridoGemm)", 100000)
+        k("void (anonymous namespace)::gn_fused_f32_kernel<1024, 1>(FridoGnApply)", 5000)
+        k("(anonymous namespace)::sampler_step_kernel(FridoSamplerStep)", 3000)
+    k("(anonymous namespace)::vq_kernel(FridoVq)", 1000)
+    (tmp_path / "x").mkdir()
+    with open(tmp_path / "x" / "1_kernel_trace.csv", "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gap_analysis.py"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    loop = json.loads(out.stdout)["sampling_loop"]
+    assert loop["forwards"] == 4 and loop["gemm_family_launches"] == 8 and loop["kernels_per_forward"] == 4.0
+    assert abs(loop["gemm_family_ms_per_forward"] - 0.15) < 1e-9 and abs(loop["forward_ms_wall"] - 0.158375) < 1e-9

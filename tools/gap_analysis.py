@@ -60,13 +60,35 @@ def main():
         per[k][0] += 1
         per[k][1] += e - s
     gaps.sort()
+    # (r06, r05 verdict next 7) the SAMPLING LOOP alone -- the kernels from the first to the last sampler_step_kernel of the pass, i.e. the
+    # replayed step graphs (denoiser forward + update + step counter) without the hoisted pre-passes' first part and without the decode:
+    # `forwards` = number of update kernels in the window (+ 1: the first forward lies before the first update), per-kernel-name totals and the
+    # GEMM family's total -- bench.py divides its own algorithmic FLOPs per forward by (family_ms / forwards) for `roofline.trace`
+    steps = [i for i, r in enumerate(rows) if "sampler_step_kernel" in r[2]]
+    loop = {}
+    if len(steps) >= 2:
+        lrows = rows[steps[0] + 1: steps[-1] + 1]
+        lper = defaultdict(lambda: [0, 0])
+        for s, e, n in lrows:
+            k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+            lper[k][0] += 1
+            lper[k][1] += e - s
+        fam = ("igemm_kernel", "conv3x3_patch_kernel", "conv3x3_gn_kernel")
+        nf = len(steps) - 1
+        loop = {"forwards": nf, "wall_ms": (lrows[-1][1] - lrows[0][0]) / 1e6, "kernels": len(lrows),
+                "kernels_per_forward": round(len(lrows) / nf, 2), "forward_ms_wall": (lrows[-1][1] - lrows[0][0]) / 1e6 / nf,
+                "gemm_family_ms": sum(v[1] for k, v in lper.items() if k in fam) / 1e6,
+                "gemm_family_launches": sum(v[0] for k, v in lper.items() if k in fam),
+                "gemm_family_ms_per_forward": sum(v[1] for k, v in lper.items() if k in fam) / 1e6 / nf,
+                "per_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(lper.items(), key=lambda kv: -kv[1][1])}}
     out = {"kernels": len(rows), "wall_ms": wall / 1e6, "busy_ms": busy / 1e6, "idle_ms": (wall - busy) / 1e6,
            "idle_frac": (wall - busy) / wall, "sum_dur_ms": sum(e - s for s, e, _ in rows) / 1e6,
            "gap_us_median": gaps[len(gaps) // 2] / 1e3 if gaps else 0, "gap_us_p90": gaps[int(len(gaps) * .9)] / 1e3 if gaps else 0,
            "n_gaps": len(gaps), "gaps_gt_5ms": [round(g / 1e6, 2) for g in gaps if g > 5_000_000],
            "bubbles_gt2us_by_preceding_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(before.items(), key=lambda kv: -kv[1][1])[:8]},
            "bubbles_gt2us_by_following_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(after.items(), key=lambda kv: -kv[1][1])[:8]},
-           "per_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}}
+           "per_kernel_ms": {k: [v[0], round(v[1] / 1e6, 3)] for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
+           "sampling_loop": loop}
     print(json.dumps(out, indent=1))
 
 

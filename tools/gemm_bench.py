@@ -15,6 +15,7 @@ from frido_amd.engine import require_gpu  # noqa: E402
 NAMES = {1: "128x128", 2: "128x192", 3: "64x64", 4: "128x64", 5: "64x192", 6: "64x128"}
 NAMES.update({k + 10: v + "k64" for k, v in list(NAMES.items())})
 NAMES.update({7: "256x128", 8: "256x256", 9: "patch256x192", 10: "patch128x192", 17: "256x128k64", 18: "128x192w8", 19: "256x192"})
+NAMES.update({31: "128x128kg2", 33: "64x64kg2", 34: "128x64kg2", 35: "64x192kg2", 36: "64x128kg2"})      # r06: K split inside the workgroup
 
 
 def main():
