@@ -15,9 +15,11 @@ import contextlib
 import os
 SIDE_STREAM = os.environ.get("FRIDO_SIDE_STREAM", "0") != "0"   # independent projections of an attention block on a side stream: measured -2.9 % (the fork / join nodes cost more than the overlap buys), off by default
 GEMM_FLAGS = int(os.environ.get("FRIDO_GEMM_FLAGS", "0"))     # FridoGemm.flags A/B switches (include/frido_hip.h)
-# r05 stagger experiment (honoured only by -DFRIDO_STAGGER_RT=1 builds of the library, results unchanged):
-# start delay in microseconds of the second resident slot of a multi-round two-per-CU GEMM launch, and the smallest grid it applies to
-STAGGER_US = float(os.environ.get("FRIDO_STAGGER_US", "0"))          # quarter-microsecond resolution, at most 63.75
+# Staggered start (r05 experiment, SHIPPED in r06: the library is built with -DFRIDO_STAGGER_RT=1; results are
+# unchanged bit for bit): start delay in microseconds of the second resident slot (dispatch ids 256 .. 511) of a multi-round two-per-CU
+# GEMM launch (>= 768 workgroups unless FRIDO_STAGGER_MIN_WG says otherwise), so that one slot's prologue / epilogue runs under the
+# other's k-loop from then on.  12 us: + 2.1 % end to end (interleaved, profiles/r06_stagger_*.txt; 8 us on the r05 boxes: + 2.0 ... 2.5 %).
+STAGGER_US = float(os.environ.get("FRIDO_STAGGER_US", "12"))         # quarter-microsecond resolution, at most 63.75; 0 = off
 STAGGER_MIN_WG = int(os.environ.get("FRIDO_STAGGER_MIN_WG", "0"))
 STAGGER_MODE = int(os.environ.get("FRIDO_STAGGER_MODE", "0"))        # 0: dispatch ids 256..511 wait; 1: every other workgroup of an XCD (control)
 STAGGER_8W = int(os.environ.get("FRIDO_STAGGER_8W", "0"))            # 1: the one-workgroup-per-CU kernels too (odd XCDs start late; igemm_shared.h)
