@@ -297,9 +297,10 @@ class Prog:
             st = self.ops[-1][1]
             choice = tune.best_tile(st, self.device, torch.cuda.current_stream(self.device).cuda_stream)
             st.tile, st.splitk = choice[0], choice[1]
-            if len(choice) > 2 and choice[2] and not STAGGER_US:
+            if len(choice) > 2 and choice[2] and "FRIDO_STAGGER_US" not in os.environ:
                 # (r05, for round 6) a pinned per-signature start delay in quarter microseconds (tools/tune_in_context.py --stagger):
-                # FridoGemm.flags bits 8..15, honoured only by -DFRIDO_STAGGER_RT=1 builds; FRIDO_STAGGER_US overrides it globally
+                # FridoGemm.flags bits 8..15 -- it replaces the library-wide default delay for this signature; an explicit FRIDO_STAGGER_US
+                # in the environment overrides every pinned delay
                 st.flags = (st.flags & ~0xFF00) | ((int(choice[2]) & 255) << 8)
             if st.splitk > 1:
                 st.sk_mode = tune.SK_MODE

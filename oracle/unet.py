@@ -12,7 +12,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from frido_amd.arch import unet_arch
+from .walk import unet_blocks
 
 
 def timestep_embedding(t, dim, max_period=10000):
@@ -115,17 +115,21 @@ def _run(p, blocks, h, emb, context, cond, depth=1):
 @torch.no_grad()
 def unet_forward(sd, cfg, x, t, context, stage, prefix="model.diffusion_model.", taps=None):
     """pyunet.py:867-950.  x: (B, sum(splits[:stage+1]), H, W); returns eps (B, splits[stage], H, W)."""
-    a = unet_arch(cfg)
+    # (r06) the block walk comes from the checkpoint's own keys (oracle/walk.py), the scalar options straight from the config -- nothing
+    # under frido_amd/ is consulted
+    input_blocks, middle, output_blocks, depth = unet_blocks(sd, prefix)
+    num_stage, splits = cfg.get("num_stage", 1), list(cfg.get("split_embed_dim_list", []))
+    use_split_head, use_spade = cfg.get("use_split_head", False), cfg.get("use_SPADE_norm", False)
     p = _P(sd, prefix)
-    emb = timestep_embedding(t, a.model_channels)
+    emb = timestep_embedding(t, cfg["model_channels"])
     emb = F.linear(emb, p("time_embed.0.weight"), p("time_embed.0.bias"))
     emb = F.linear(F.silu(emb), p("time_embed.2.weight"), p("time_embed.2.bias"))
-    if a.num_stage > 1:
+    if num_stage > 1:
         emb = emb + p("stage_emb.weight")[stage][None]
     cond = None
-    if a.use_split_head:
-        c0 = sum(a.splits[:stage]) if a.use_spade else 0
-        c1 = sum(a.splits[:stage + 1])
+    if use_split_head:
+        c0 = sum(splits[:stage]) if use_spade else 0
+        c1 = sum(splits[:stage + 1])
         h = _conv(p, f"pre_input_blocks.{stage}.0", x[:, c0:c1])
         if c0:
             cond = _conv(p, f"pre_input_cond_blocks.{stage - 1}.0", x[:, :c0])
@@ -134,19 +138,19 @@ def unet_forward(sd, cfg, x, t, context, stage, prefix="model.diffusion_model.",
     if taps is not None:
         taps["pre"] = h
     hs = [h]
-    for i, blk in enumerate(a.input_blocks):
-        h = _run(p, blk, h, emb, context, cond, a.transformer_depth)
+    for i, blk in enumerate(input_blocks):
+        h = _run(p, blk, h, emb, context, cond, depth)
         hs.append(h)
         if taps is not None and i == 0:
             taps["ib0"] = h
-    h = _run(p, a.middle, h, emb, context, cond, a.transformer_depth)
+    h = _run(p, middle, h, emb, context, cond, depth)
     if taps is not None:
         taps["mid"] = h
-    for blk in a.output_blocks:
+    for blk in output_blocks:
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run(p, blk, h, emb, context, cond, a.transformer_depth)
+        h = _run(p, blk, h, emb, context, cond, depth)
     if taps is not None:
         taps["ob_last"] = h
-    o = f"out.{stage}" if a.use_split_head else "out"
+    o = f"out.{stage}" if use_split_head else "out"
     h = F.group_norm(h, 32, p(o + ".0.weight"), p(o + ".0.bias"), 1e-5)
     return _conv(p, o + ".2", F.silu(h))

@@ -6,7 +6,7 @@ prefix in a full checkpoint).
 import torch
 import torch.nn.functional as F
 
-from frido_amd.arch import decoder_arch, encoder_arch
+from .walk import decoder_blocks, encoder_blocks
 
 
 class _P:
@@ -79,9 +79,8 @@ def quantize(codebook, z):
 
 def decoder_forward(p, dd, z, prefix="decoder"):
     """model.py:618-649."""
-    a = decoder_arch(dd, prefix)
     h = _conv(p, prefix + ".conv_in", z)
-    h = _run(p, a.body, h)
+    h = _run(p, decoder_blocks(p.sd, p.prefix, prefix), h)        # (r06: the block list is read off the checkpoint's keys, oracle/walk.py; `dd` is no longer consulted)
     h = F.silu(_gn(p, prefix + ".norm_out", h))
     return _conv(p, prefix + ".conv_out", h)
 
@@ -106,10 +105,11 @@ def vq_decode(sd, cfg, h_in, prefix="first_stage_model.", return_code=False):
 
 def encoder_forward(p, ed, x, prefix="encoder"):
     """model.py:512-546 (MSEncoder.forward): returns the `multiscale` head outputs, fine first."""
-    a = encoder_arch(ed, prefix)
+    down, heads = encoder_blocks(p.sd, p.prefix, prefix)      # (r06: read off the checkpoint's keys, oracle/walk.py)
+    multiscale = len(heads)
     h = _conv(p, prefix + ".conv_in", x)
     level_out = []
-    for blocks in a.down:
+    for blocks in down:
         for b in blocks:
             if b.kind == "down":
                 level_out.append(h)
@@ -117,9 +117,9 @@ def encoder_forward(p, ed, x, prefix="encoder"):
         if blocks[-1].kind != "down":
             level_out.append(h)
     outs = []
-    for i in range(a.multiscale):
-        h = level_out[-(a.multiscale - i)]
-        h = _run(p, a.heads[i], h)
+    for i in range(multiscale):
+        h = level_out[-(multiscale - i)]
+        h = _run(p, heads[i], h)
         h = F.silu(_gn(p, f"{prefix}.norm_out_ms.{i}", h))
         outs.append(_conv(p, f"{prefix}.conv_out_ms.{i}", h))
     return outs

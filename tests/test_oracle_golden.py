@@ -298,3 +298,34 @@ def test_oracle_heavy_profile_unet_vq_sampler():
         out, _ = fn(am, ac, int(Sx), (2, 6, 16, 16), c, [3, 3], [3, 3], 2, scale=float(scale), uc=torch.zeros_like(c),
                     noise=S.NoiseSource(gs[f"{run}_noise"]), log_every_t=int(lev), **kw)
         assert torch.equal(out, torch.from_numpy(gs[f"{run}_samples"])), run
+
+
+def test_oracle_block_walk_is_its_own_and_agrees_with_the_product_walk():
+    """(r06, r05 verdict hygiene) The oracle reads its block list off the CHECKPOINT KEYS (oracle/walk.py: children in index order, kind from
+    the parameter names a child owns -- how the reference's nn.Sequential containers execute), and imports nothing under frido_amd/.  The
+    product's plan builders walk frido_amd/arch.py (a restatement of the constructor loops).  Two independent readings: they must list the
+    same blocks, in the same order, under the same prefixes, for every configuration a fixture uses."""
+    import ast
+    import os
+    from golden_cfg import UNET_F16F8, UNET_512, VQ_F16F8, VQ_512
+    from frido_amd.arch import decoder_arch, encoder_arch, unet_arch
+    from oracle import walk
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in sorted(os.listdir(os.path.join(root, "oracle"))):
+        if name.endswith(".py"):
+            tree = ast.parse(open(os.path.join(root, "oracle", name)).read())
+            mods = [n.module or "" for n in ast.walk(tree) if isinstance(n, ast.ImportFrom)] + [a.name for n in ast.walk(tree) if isinstance(n, ast.Import) for a in n.names]
+            assert not [m for m in mods if m.split(".")[0] in ("frido_amd", "frido", "taming", "ldm")], (name, mods)
+    flat = lambda groups: [[(b.kind, b.prefix) for b in g] for g in groups]
+    for cfg in (UNET_SMALL, UNET_SMALL_D2, UNET_SMALL3, UNET_FULL, UNET_F16F8, UNET_512):
+        sd = {"model.diffusion_model." + k: None for k in unet_holder(cfg).state_dict()}
+        ib, mid, ob, depth = walk.unet_blocks(sd, "model.diffusion_model.")
+        a = unet_arch(cfg)
+        assert flat(ib) == flat(a.input_blocks) and flat([mid]) == flat([a.middle]) and flat(ob) == flat(a.output_blocks)
+        assert depth == a.transformer_depth
+    for cfg in (VQ_SMALL, VQ_SMALL3, VQ_FULL, VQ_F16F8, VQ_512):
+        sd = {"first_stage_model." + k: None for k in vq_holder(cfg).state_dict()}
+        assert flat([walk.decoder_blocks(sd, "first_stage_model.")]) == flat([decoder_arch(cfg["ddconfig"]).body])
+        down, heads = walk.encoder_blocks(sd, "first_stage_model.")
+        e = encoder_arch(cfg["edconfig"])
+        assert flat(down) == flat(e.down) and flat(heads) == flat(e.heads)

@@ -100,7 +100,8 @@ def test_pinned_cache_entry_may_carry_a_start_delay(monkeypatch):
         p = engine.Prog(torch.device("cuda"), 2)
         p.gemm(16384, 3072, 384, (0x1000, 64), (0x2000, 64), out_f32=0x3000, ldo=3072)
         st = p.ops[-1][1]
-        assert (st.tile, st.splitk) == choice[:2] and st.flags == (engine.GEMM_FLAGS | want)
+        # a pinned delay REPLACES the library-wide default (engine.STAGGER_US, bits 8..15 of GEMM_FLAGS); without one the default stands
+        assert (st.tile, st.splitk) == choice[:2] and st.flags == (((engine.GEMM_FLAGS & ~0xFF00) | want) if want else engine.GEMM_FLAGS)
 
 
 def test_trace_diff_groups_by_kernel_and_grid(tmp_path, capsys):

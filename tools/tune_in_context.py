@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FOUR_WAVE = (1, 2, 3, 4, 5, 6)
 EIGHT_WAVE = (7, 18, 19)          # bf16x3 mode (frido_hip.h FridoGemm.tile)
+KG2_DIMS = {31: (128, 128), 33: (64, 64), 34: (128, 64), 35: (64, 192), 36: (64, 128)}      # K split over the two wave groups of one workgroup (r06)
 TILE_DIMS = {1: (128, 128), 2: (128, 192), 3: (64, 64), 4: (128, 64), 5: (64, 192), 6: (64, 128)}      # the two-per-CU (4-wave) tiles
 
 
@@ -40,11 +41,15 @@ def set_stagger(st, quarter_us):
 
 def candidates(st):
     """Tiles worth trying for a descriptor: the filter of tune.best_tile, split-K left as it is."""
-    if st.nsplit != 2 or st.tile in (0, 9, 10, 20, 21) or st.tile > 19 or st.splitk > 1 or st.up2_phase:
+    if st.nsplit != 2 or st.tile in (0, 9, 10, 20, 21) or (st.tile > 19 and st.tile not in KG2_DIMS) or st.splitk > 1 or st.up2_phase:
         return []           # fused GroupNorm + conv / patch kernels / split-K launches (workspace layout may depend on the tile) stay
     out = [t for t in FOUR_WAVE if not (t in (1, 2, 4) and st.M < 64)]
     if st.M >= 512 and st.N >= 96:
         out += list(EIGHT_WAVE)
+    nk = (st.K + st.K2) // 32
+    if not st.conv and nk >= 2 and nk % 2 == 0:      # (r06) K split inside the workgroup: sub-round dense launches only (tune.py's filter)
+        out += [t for t, (bm, bn) in KG2_DIMS.items()
+                if not (t in (31, 34) and st.M < 64) and -(-st.M // bm) * -(-st.N // bn) * max(st.batch, 1) <= 640]
     return [t for t in out if t != st.tile]
 
 
