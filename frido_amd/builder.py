@@ -14,6 +14,7 @@ from .engine import (Operand, POperand, F32, Alias, Pool, Prog, pack_matrix, pac
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 UP2_PHASES = os.environ.get("FRIDO_UP2_PHASES", "1") != "0"       # Upsample convs as four 2x2 phase convolutions
 GN_FUSED = os.environ.get("FRIDO_GN_FUSED", "1") != "0"          # one-launch GroupNorm (norm.hip gn_fused_kernel)
+GN_CONV_TINY = os.environ.get("FRIDO_GN_CONV_TINY", "1") != "0"     # r06: the eps head (GroupNorm + SiLU + conv3x3 to 3 / 4 channels) as ONE f32 VALU launch (tile 40)
 GN_FUSED_MAX_HW = int(os.environ.get("FRIDO_GN_FUSED_MAX_HW", "256"))   # larger planes: gn_stats + gn_apply are faster
 # r04: a split-K GEMM whose output goes straight into a one-launch GroupNorm leaves its reduction to that launch (no splitk_reduce)
 SK_DEFER = os.environ.get("FRIDO_SK_DEFER", "1") != "0"
@@ -448,6 +449,31 @@ class Builder:
             st.ws = tune.workspace_for(st, self.device, self.prog.ws_tag + (":s1" if self.prog._sid else ""))
         self.pool.release(part)
         return res
+
+    def gn_conv_tiny_ok(self, x, B, H, W, co):
+        """The fused GroupNorm + SiLU + 3x3 conv with a TINY output width (FridoGemm tile 40: the denoiser's eps head) applies."""
+        return (GN_CONV_TINY and self.nsplit == 2 and self.device.type == "cuda" and not getattr(x, "bf16", False) and co in (3, 4)
+                and x.C % 32 == 0 and x.C <= 960 and W in (16, 32, 64) and (H * W) % 256 == 0 and (256 // W + 2) * (W + 2) <= 396)
+
+    def gn_conv_tiny(self, x, B, H, W, norm_w, eps, conv_w, out, act=ACT_SILU):
+        """out[B*H*W][co] = conv3x3(act(GroupNorm32(x))) + bias with co in {3, 4}, ONE launch on the f32 VALU after the GroupNorm statistics
+        (csrc/convgn.hip conv3x3_gn_tiny_kernel; pyunet.py:775-803 `out`).  Weights go in as f32 [C / 32][9 taps][co][32 channels]."""
+        key = ("tinyconv", conv_w)
+        if key not in self._wcache:
+            w = self.w[conv_w + ".weight"].float()                      # [co][C][3][3]
+            co, C = w.shape[0], w.shape[1]
+            wt = w.permute(1, 2, 3, 0).reshape(C // 32, 32, 9, co).permute(0, 2, 3, 1).contiguous()      # [C/32][9][co][32]
+            self._wcache[key] = self.to_dev(wt)
+        wt = self._wcache[key]
+        co, C = self.w[conv_w + ".weight"].shape[0], x.C
+        part, S = self.gn_stats(x, None, B, H * W)
+        gn = dict(gn_x1=x.ptr, gn_C1=C, gn_partials=part.data_ptr(), gn_nsplit_px=S, gn_groups=32, gn_eps=eps,
+                  gn_weight=self.bias(norm_w + ".weight"), gn_bias=self.bias(norm_w + ".bias"), gn_act=act, w_f32=wt.data_ptr())
+        geom = dict(Hs=H, Ws=W, Cin=C, Hl=H, Wl=W, Ho=H, Wo=W, kh=3, kw=3, stride=1, pad=1, up_shift=0, dn_shift=0)
+        self.prog.gemm(B * H * W, co, 9 * C, None, (None, 0), ldb=9 * C, conv=geom, bias=self.bias(conv_w + ".bias"), out_f32=out.ptr, ldo=out.C,
+                       tile=40, gn=gn)
+        self.pool.release(part)
+        return out
 
     def gn_stats(self, x1, x2, B, HW):
         p1, p2 = getattr(x1, "gn_part", None), getattr(x2, "gn_part", None) if x2 is not None else None

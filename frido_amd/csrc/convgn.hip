@@ -521,7 +521,202 @@ int launch_convgn_bm(const FridoGemm& d, hipStream_t s) {
     return frido_check_launch("conv3x3_gn");
 }
 
+
+// =====================================================================================================================
+// conv3x3_gn_tiny_kernel (r06, FridoGemm tile 40): the denoiser's OUTPUT HEAD  eps = conv3x3( SiLU( GroupNorm32(h) ) )  with N = 3 or 4
+// output channels (pyunet.py:775-803: `out` = normalization, SiLU, conv_nd(model_channels, out_channels, 3, padding=1); one per stage with
+// the split head).  On the MFMA family this conv was the worst launch of the forward: a 64-column tile computes 61 dead columns, the
+// normalised operand (50 MB of hi / lo planes at 64^2 x 192) is written by gn_apply and pulled through L2 -> LDS nine times, and the K
+// walk needs split-K + a reduction launch -- 21 + 77 us per forward at 8.8 TFLOP/s.  Here the whole head is ONE launch on the f32 VALU:
+//   * tile = 256 output pixels (R = 256 / W image rows); per 32-channel chunk the (R + 2) x (W + 2) patch is read ONCE from the f32 stream,
+//     normalised (gn_apply_kernel's expressions: x * sc + sh, SiLU) and parked in LDS as f32 (zero halo = the conv pads the ACTIVATION);
+//     the next chunk's global loads are in flight while the current one is multiplied;
+//   * a thread owns one pixel and N accumulators: 9 taps x 32 channels x N fmaf per chunk; activations come from LDS (slot stride 36 floats:
+//     conflict-free ds_read_b128 for consecutive pixels), WEIGHTS FROM THE SCALAR CACHE (s_load_dwordx8, wave-uniform addresses): they cost
+//     no LDS and no VALU, an FMA takes them as its SGPR operand;
+//   * plain f32 accumulation (exact products, 24-bit sums): at least as accurate as the two-plane path it replaces.
+// 65536 x 192 -> 3: 340 MFLOP, 50 MB read once -> HBM / VALU balanced at ~15 us.
+template <int NO>
+__global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d, const float* __restrict__ wq) {      // wq = d.w_f32 as a noalias argument: wave-uniform loads from it become s_load
+    constexpr int NT = 256, SS = 36, MAXSLOTS = 396, MAXC = 960;      // SS: floats per patch slot (32 channels + 4 pad)
+    constexpr int NRD = (MAXSLOTS * 4 + NT - 1) / NT;                  // staging rounds per chunk (8-channel units per thread): 7
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* const patch = reinterpret_cast<float*>(smem);               // [MAXSLOTS][SS]
+    float* const tab_sc = patch + MAXSLOTS * SS;
+    float* const tab_sh = tab_sc + MAXC;
+    float* const wl = tab_sh + MAXC;                                    // this chunk's weights [9 taps][128] (NO x 32 used)
+    const int t = threadIdx.x;
+    const int W = d.Ws, H = d.Hs, HW = H * W;
+    const int R = NT / W, PW = W + 2, PS = (R + 2) * PW;
+    const int m0 = (int)blockIdx.x * NT;
+    const int img = m0 / HW, y0 = (m0 - img * HW) / W;
+    const int C = d.gn_C1;
+    const float* __restrict__ x1 = d.gn_x1;
+
+    // ---- GroupNorm statistics -> per-channel scale / shift (conv3x3_gn_kernel's prologue: same order, same expressions) ----
+    {
+        float* s_mean = patch;
+        float* s_rstd = s_mean + 64;
+        const int cpg = C / d.gn_groups;
+        double* s_part = reinterpret_cast<double*>(smem + 1024);
+        {
+            const int g = t & 31, l8 = t >> 5;
+            double s = 0.0, q = 0.0;
+            if (g < d.gn_groups) {
+                for (int k = 0; k < 8; ++k) {
+                    const int sp = l8 + 8 * k;
+                    if (sp < d.gn_nsplit_px) {
+                        const double2 pv = *reinterpret_cast<const double2*>(d.gn_partials + (((int64_t)img * d.gn_nsplit_px + sp) * d.gn_groups + g) * 2);
+                        s += pv.x;
+                        q += pv.y;
+                    }
+                }
+                s_part[(l8 * 32 + g) * 2] = s;
+                s_part[(l8 * 32 + g) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < d.gn_groups) {
+            double s = 0.0, q = 0.0;
+            for (int l = 0; l < 8; ++l) { s += s_part[(l * 32 + t) * 2]; q += s_part[(l * 32 + t) * 2 + 1]; }
+            const double n = (double)HW * cpg;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mean[t] = (float)mean;
+            s_rstd[t] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
+            if (blockIdx.x == 0) status_raise(false, stat_bad(s_mean[t], s_rstd[t]));
+        }
+        __syncthreads();
+        for (int c = t; c < C; c += NT) {
+            const int g = c / cpg;
+            const float sc = s_rstd[g] * d.gn_weight[c];
+            tab_sc[c] = sc;
+            tab_sh[c] = d.gn_bias[c] - s_mean[g] * sc;
+        }
+        __syncthreads();
+    }
+
+    // ---- staging geometry: unit (round r) = patch slot r * 64 + (t >> 2), channels (t & 3) * 8 of the chunk ----
+    const int cu = (t & 3) * 8;
+    int pix[NRD];                                       // global pixel, -1: halo (zeros), -2: beyond the patch
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) {
+        const int slot = r * 64 + (t >> 2);
+        const int pr = slot / PW, px = slot - pr * PW;
+        const int y = y0 + pr - 1, x = px - 1;
+        pix[r] = slot >= PS ? -2 : ((y >= 0 && y < H && x >= 0 && x < W) ? img * HW + y * W + x : -1);
+    }
+    const bool do_silu = d.gn_act == FRIDO_ACT_SILU;
+    float4 pre[NRD][2];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRD; ++r)
+            if (pix[r] >= 0) {
+                const float* src = x1 + (int64_t)pix[r] * C + c * 32 + cu;
+                pre[r][0] = *reinterpret_cast<const float4*>(src);
+                pre[r][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+    };
+    auto park_chunk = [&](int c) {
+        for (int i = t; i < 9 * NO * 32; i += NT) wl[(i / (NO * 32)) * 128 + i % (NO * 32)] = wq[(int64_t)c * (9 * NO * 32) + i];
+        const float4 a0 = *reinterpret_cast<const float4*>(tab_sc + c * 32 + cu), a1 = *reinterpret_cast<const float4*>(tab_sc + c * 32 + cu + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(tab_sh + c * 32 + cu), b1 = *reinterpret_cast<const float4*>(tab_sh + c * 32 + cu + 4);
+        const float sc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int r = 0; r < NRD; ++r) {
+            if (pix[r] == -2) continue;
+            float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (pix[r] >= 0) {
+                const float xin[8] = {pre[r][0].x, pre[r][0].y, pre[r][0].z, pre[r][0].w, pre[r][1].x, pre[r][1].y, pre[r][1].z, pre[r][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    y[e] = fmaf(xin[e], sc[e], sh[e]);
+                    if (do_silu) y[e] = silu_f(y[e]);
+                }
+            }
+            float* dst = patch + (r * 64 + (t >> 2)) * SS + cu;
+            *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+    };
+
+    // ---- this thread's output pixel: centre slot in the patch ----
+    const int prow = t / W, pcol = t - prow * W;
+    const int sc0 = (prow + 1) * PW + (pcol + 1);
+    float acc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+    const int nch = C >> 5;
+    load_chunk(0);
+    park_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) load_chunk(c + 1);              // in flight under this chunk's multiply
+        // One tap = NO x 32 weights, the same for every pixel: lane l of a wave fetches weights l and 64 + l of the tap from LDS (two
+        // conflict-free ds_read_b32) and every FMA takes its weight out of those two registers with v_readlane_b32 -> SGPR operand.  (Tried
+        // first: s_load_dwordx16 from global -- the 20-KB weight set thrashes the scalar cache, 97 us per launch; 24 broadcast ds_read_b128
+        // per tap would make the launch LDS-bound at ~23 us.)  NOT unrolled over taps: registers.
+        const int lane = t & 63;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const float w0 = wl[tap * 128 + lane], w1 = wl[tap * 128 + 64 + lane];
+            const float* ap = patch + (sc0 + (tap / 3 - 1) * PW + (tap % 3 - 1)) * SS;
+            float a[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(ap + 4 * q);
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 32; ++e)
+#pragma unroll
+                for (int n = 0; n < NO; ++n) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int idx = n * 32 + e;
+                    const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idx < 64 ? w0 : w1), idx & 63));
+                    acc[n] = fmaf(a[e], wv, acc[n]);
+                }
+        }
+        __syncthreads();                                 // every thread is done reading the patch
+        if (c + 1 < nch) {
+            park_chunk(c + 1);
+            __syncthreads();
+        }
+    }
+    const int m = m0 + t;
+    if (m < d.M) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n)
+            if (n < d.N) d.out_f32[(int64_t)m * d.ldo + n] = d.alpha * acc[n] + (d.bias ? d.bias[n] : 0.f);
+    }
+}
+
+bool convgn_tiny_ok(const FridoGemm& d) {
+    if (!d.conv || d.nsplit != 2 || d.batch != 1 || !d.gn_x1 || d.gn_x2 || d.gn_C2 || !d.gn_partials || !d.gn_weight || !d.gn_bias || !d.w_f32) return false;
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.padx != 1 || d.up_shift || d.dn_shift || d.up2_phase || d.splitk > 1) return false;
+    if (d.Ho != d.Hs || d.Wo != d.Ws || d.Hl != d.Hs || d.Wl != d.Ws) return false;
+    const int W = d.Ws, HW = d.Hs * d.Ws, C = d.gn_C1;
+    if (W < 16 || W > 64 || (W & (W - 1)) || HW % 256 || d.M % 256 || (256 / W + 2) * (W + 2) > 396) return false;
+    if ((C & 31) || C != d.Cin || C > 960 || d.K != 9 * d.Cin || d.K2) return false;
+    if (d.gn_groups <= 0 || d.gn_groups > 32 || C % d.gn_groups || d.gn_nsplit_px < 1 || d.gn_nsplit_px > 64) return false;
+    if (d.gn_gamma || d.gn_beta || (d.N != 3 && d.N != 4)) return false;
+    if (!d.out_f32 || d.out_bf16 || d.out_op || d.out_u8 || d.residual || d.rowvec || d.row_bias || d.geglu || d.gn_part || d.act != FRIDO_ACT_NONE || d.ldo < d.N) return false;
+    return true;
+}
+constexpr int CG_TINY_SMEM = (396 * 36 + 2 * 960 + 9 * 128) * 4;
+
 }  // namespace
+
+int frido_launch_convgn_tiny(const FridoGemm& d, hipStream_t s) {
+    if (!convgn_tiny_ok(d)) {
+        frido_set_error("igemm: tile 40 (fused GroupNorm + 3x3 conv with 3 / 4 output channels) does not apply to this descriptor");
+        return FRIDO_EINVAL;
+    }
+    if (d.N == 3) hipLaunchKernelGGL((conv3x3_gn_tiny_kernel<3>), dim3(d.M / 256), dim3(256), CG_TINY_SMEM, s, d, d.w_f32);
+    else hipLaunchKernelGGL((conv3x3_gn_tiny_kernel<4>), dim3(d.M / 256), dim3(256), CG_TINY_SMEM, s, d, d.w_f32);
+    return frido_check_launch("conv3x3_gn_tiny");
+}
 
 int frido_launch_convgn(const FridoGemm& d, int bm, hipStream_t s) {
     if (!convgn_ok(d, bm)) {
@@ -540,6 +735,9 @@ int convgn_attr() {
 }  // namespace
 
 int frido_convgn_init() {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_gn_tiny_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, CG_TINY_SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_gn_tiny_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CG_TINY_SMEM) != hipSuccess)
+        return 1;
     return convgn_attr<256, false, false>() | convgn_attr<256, false, true>() | convgn_attr<256, true, false>() | convgn_attr<256, true, true>() |
            convgn_attr<128, false, false>() | convgn_attr<128, false, true>() | convgn_attr<128, true, false>() | convgn_attr<128, true, true>();
 }

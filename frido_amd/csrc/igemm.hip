@@ -27,6 +27,7 @@
 
 // convgn.hip: the fused GroupNorm + 3x3 conv kernel (tiles 20 / 21)
 int frido_launch_convgn(const FridoGemm& d, int bm, hipStream_t s);
+int frido_launch_convgn_tiny(const FridoGemm& d, hipStream_t s);      // tile 40
 int frido_convgn_init();
 
 // Timing ablations of the bf16x3 main loop (tools/build_ablate.sh builds SEPARATE libraries with -DFRIDO_ABLATE=<mask>; the shipped
@@ -1477,8 +1478,11 @@ int dispatch_tile(const FridoGemm& d, int tile, hipStream_t s) {
             return rc;
         }
     }
+    if constexpr (NS == 2 && CONV) {
+        if (tile == 40) return frido_launch_convgn_tiny(d, s);
+    }
     if (d.gn_x1) {
-        frido_set_error("igemm: a descriptor with a fused GroupNorm input (gn_x1) runs on tile 20 or 21 only");
+        frido_set_error("igemm: a descriptor with a fused GroupNorm input (gn_x1) runs on tile 20, 21 or 40 only");
         return FRIDO_EINVAL;
     }
     switch (tile) {
@@ -1605,8 +1609,8 @@ extern "C" int frido_gemm(const FridoGemm* dp, frido_stream_t stream) {
     FRIDO_REQUIRE((d.K & 31) == 0 && (d.K2 & 63) == 0, "K must be a multiple of 32, K2 of 64 (zero-pad the operands)");
     FRIDO_REQUIRE(d.K2 == 0 || (((d.A2 && (d.lda2 & 7) == 0) || (d.gn_x1 && d.raw_x1)) && (d.K & 63) == 0 && d.batch == 1), "bad second A operand");
     FRIDO_REQUIRE(d.nsplit == 1 || d.nsplit == 2, "nsplit must be 1 or 2");
-    FRIDO_REQUIRE((d.A || d.gn_x1) && d.B, "null operand");
-    FRIDO_REQUIRE(!d.gn_x1 || d.tile == 20 || d.tile == 21, "a fused GroupNorm input (gn_x1) needs tile 20 or 21");
+    FRIDO_REQUIRE((d.A || d.gn_x1) && (d.B || (d.tile == 40 && d.w_f32)), "null operand");
+    FRIDO_REQUIRE(!d.gn_x1 || d.tile == 20 || d.tile == 21 || d.tile == 40, "a fused GroupNorm input (gn_x1) needs tile 20, 21 or 40");
     FRIDO_REQUIRE(d.out_f32 || d.out_op || d.out_u8, "no output");
     FRIDO_REQUIRE(!d.out_u8 || ((d.u8_mode == 1 || d.u8_mode == 2) && d.ldu8 >= d.N && d.splitk <= 1 && !d.gn_part && !d.geglu && !d.up2_phase &&
                                 d.batch == 1),

@@ -6,6 +6,8 @@
                      (reference: frido/models/diffusion/ddim.py:116-273, plms.py:116-303);
   DecoderRuntime   — VQModelInterface.decode / decode_first_stage on the HIP engine.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -15,6 +17,9 @@ from .engine import current_stream_ptr, require_gpu
 from .schedules import sampler_coef_table
 from .unet_plan import UNetStagePlan
 from .vqgan_plan import VQDecodePlan, VQEncodePlan
+
+# step bodies per captured DDIM graph (1 = one graph launch per step, the r01-r05 form); see SamplerEngine._ddim_stage
+GRAPH_STEPS = max(1, int(os.environ.get("FRIDO_GRAPH_STEPS", "1")))
 
 
 def _weights_of(module, device):
@@ -302,9 +307,30 @@ class SamplerEngine:
                 self.graphs[key] = full.capture(sp) if self.use_graph else full
             g = self.graphs[key]
             launch = (lambda: g.launch(sp)) if self.use_graph else (lambda: g.run(sp))
-        for i in range(n):
-            launch()
-            self._log(s, i, inter, log_every_t, sp, Cs, callback, img_callback)
+        # (r06) GRAPH_STEPS > 1: the same step body K times in ONE captured graph (the device step counter makes every repetition pick its own
+        # timestep / noise slice), replayed wherever the K - 1 steps in between need no host access (log / callbacks): fewer graph launches --
+        # the trace shows ~30 us between the last kernel of one replay and the first of the next (profiles/r05_x3_gap_analysis.json)
+        K = GRAPH_STEPS if self.use_graph else 1
+        gk = None
+        if K > 1 and n >= K and callback is None and img_callback is None:
+            kkey = key + ("x%d" % K,)
+            if kkey not in self.graphs:
+                from .engine import Prog
+                multi = Prog(self.dev, self.b.nsplit)
+                multi.ops = list(g.keep[1].ops) * K          # (Graph.keep = (packed descriptor array, the Prog it was captured from))
+                multi.keep = [plan]
+                self.graphs[kkey] = multi.capture(sp)
+            gk = self.graphs[kkey]
+        needs_host = lambda i: (n - i - 1) % log_every_t == 0 or i == n - 1          # what _log does at step i without callbacks
+        i = 0
+        while i < n:
+            if gk is not None and i + K <= n and not any(needs_host(j) for j in range(i, i + K - 1)):
+                gk.launch(sp)
+                i += K
+            else:
+                launch()
+                i += 1
+            self._log(s, i - 1, inter, log_every_t, sp, Cs, callback, img_callback)
 
     def _corrected_eps(self, s, sp, Cs, t_value, opts):
         """`score_corrector.modify_score(model, e_t, x, t, c, **kwargs)` (ddim.py:228-230, plms.py:236-238) on the eps the forward

@@ -33,14 +33,16 @@ CACHE_FILE = os.environ.get("FRIDO_TUNE_CACHE", "")
 # benchmark's pinned tiles, every other shape a deterministic one, so a run of the suite is bitwise repeatable on any box
 ON_MISS = os.environ.get("FRIDO_TUNE_ON_MISS", "tune")
 _dirty = False
-KG2 = os.environ.get("FRIDO_TUNE_KG2", "1") != "0"
+# measured (profiles/r06_kg2_*, r06_tune_in_context.log): the back-to-back microbenchmark prefers a KG2 tile on 11 signatures (e.g. 4096 x 576 x 576: 22.7 -> 21.8 us),
+# IN CONTEXT the 4-wave tile wins them back (-5 ... -9 % per launch) and end to end the two caches tie (3.362 vs 3.368 images/s): OFF by default
+KG2 = os.environ.get("FRIDO_TUNE_KG2", "0") != "0"
 TILES_KG2 = (31, 33, 34, 35, 36)
 KG2_DIMS = {31: (128, 128), 33: (64, 64), 34: (128, 64), 35: (64, 192), 36: (64, 128)}
 KG2_MAX_WG = int(os.environ.get("FRIDO_TUNE_KG2_MAX_WG", "640"))
 
 
 def _lib_tag():
-    if os.environ.get("FRIDO_TUNE_TAG"):      # A/B of two library builds with the SAME pinned tiles (tools/ab_lib.sh)
+    if os.environ.get("FRIDO_TUNE_TAG"):      # A/B of two library builds with the SAME pinned tiles (tools/ab.sh lib)
         return os.environ["FRIDO_TUNE_TAG"]
     mode = f"+sk{SK_MODE}" if SK_MODE else ""       # tiles tuned under another split-K reduction are not comparable
     try:
@@ -154,7 +156,12 @@ def best_tile(st, device, stream):
     C.memmove(C.addressof(t), C.addressof(st), C.sizeof(G))
     ns = st.nsplit
     t.gn_part = None         # candidates are timed without the fused GroupNorm partial sums (split-K tiles cannot produce them)
-    t.up2_phase = 0          # timed with in-order output rows: the scratch output is M x N, not the interleaved 4M x N
+    # (r06) an all-phases upsample conv (up2_phase 5: batch index = phase) keeps its form while it is timed -- until r05 the phase flag was
+    # cleared here while batch = 4 stayed, a combination frido_gemm REJECTS ("conv mode is not batched"): every candidate failed and the three
+    # upsample convs of a forward ran on the static tile (8^2 -> 16^2: 128 x 192 tiles = 160 workgroups, 181 TFLOP/s).  Its scratch output is the
+    # interleaved [4 M][N] tensor; a single-phase conv (1..4) is timed as a plain conv with in-order rows.
+    if st.up2_phase != 5:
+        t.up2_phase = 0
     if st.conv:
         a_elems = (st.M // (st.Ho * st.Wo)) * st.Hs * st.Ws * st.Cin
     else:
@@ -171,9 +178,9 @@ def best_tile(st, device, stream):
         t.A2, t.a2_lo = _buf("A2", a2 * 2 * ns, device), a2
     rows = st.M * st.batch
     if st.out_f32:
-        t.out_f32 = _buf("O", max(max(st.of_bs, st.of_bs2) * st.batch, st.M * st.ldo) * 4 + 4096, device)
+        t.out_f32 = _buf("O", max(max(st.of_bs, st.of_bs2) * st.batch, st.M * st.ldo * (4 if st.up2_phase == 5 else 1)) * 4 + 4096, device)
     if st.out_op:
-        n = max(max(st.oo_bs, st.oo_bs2) * st.batch, st.M * st.ldoo) + 4096
+        n = max(max(st.oo_bs, st.oo_bs2) * st.batch, st.M * st.ldoo * (4 if st.up2_phase == 5 else 1)) + 4096
         n = (n + 7) // 8 * 8
         t.out_op, t.oo_lo = _buf("OO", n * 2 * ns, device), n
     if st.residual:
@@ -234,6 +241,12 @@ def best_tile(st, device, stream):
             dt = sorted(list(ms)[1:])[reps // 2]
             if dt < best_t:
                 best, best_t = (tile, sk), dt
+    if best_t == float("inf"):
+        # (r06) every candidate was rejected by the library: the launch falls back to the static tile.  That is how the upsample convs
+        # silently ran untuned for three rounds -- say so.
+        import warnings
+        warnings.warn(f"frido_amd.tune: no candidate tile could be timed for GEMM M={st.M} N={st.N} K={st.K}+{st.K2} batch={st.batch} "
+                      f"conv={st.conv} up2_phase={st.up2_phase} ({L.frido_last_error().decode()}): it runs on the library's static tile")
     _cache[sig] = best
     global _dirty
     if _lib.active_planes() == "f16":

@@ -404,9 +404,16 @@ class UNetStagePlan:
                 cur, first = nxt, False
         assert not hs
         o = f"out.{s}" if a.use_split_head else "out"
+        eps_out = self._T(self.eps)
+        if b.gn_conv_tiny_ok(cur, self.Bx, h, w, eps_out.C):
+            # (r06) the eps head as ONE launch: GroupNorm statistics (from the producer's partial sums) + conv3x3_gn_tiny_kernel.  Until r05:
+            # gn_apply (50 MB of operand planes written) + a 64-column MFMA tile for 3 live columns under split-K + its reduction
+            b.gn_conv_tiny(cur, self.Bx, h, w, o + ".0", 1e-5, o + ".2", eps_out)
+            cur.free()
+            return prog
         ao, _ = b.groupnorm(cur, None, self.Bx, h * w, o + ".0", 1e-5, act=ACT_SILU)
         cur.free()
-        b.conv(ao, self.Bx, h, w, o + ".2", out=("f32", self._T(self.eps)))
+        b.conv(ao, self.Bx, h, w, o + ".2", out=("f32", eps_out))
         ao.free()
         return prog
 

@@ -127,6 +127,8 @@ typedef struct FridoGemm {
                                    11..16 = the same shapes with BK 64 (bf16 mode, K and Cin multiples of 64), 17 = 256x128 with BK 64;
                                    18 = 128x192 on eight waves, 19 = 256x192 on eight waves (bf16x3 mode);
                                    20 = 256x192 / 21 = 128x192 with the GroupNorm-apply fused in (gn_* below, bf16x3 mode);
+                                   40 (r06) = fused GroupNorm [+ SiLU] + 3x3 conv with N = 3 or 4 output channels on the f32 VALU (gn_* + w_f32
+                                   below; no MFMA, no operand planes: the denoiser's eps head);
                                    31 / 33 / 34 / 35 / 36 (r06) = tiles 1 / 3 / 4 / 5 / 6 with K split over the TWO wave groups of one 8-wave
                                    workgroup (partial tiles added through LDS, acc0 + acc1): dense bf16x3 GEMMs with an even number of
                                    32-deep k-tiles and splitk <= 1 -- for launches of fewer workgroups than the chip has CU slots */
@@ -160,6 +162,9 @@ typedef struct FridoGemm {
     const float* gn_weight; const float* gn_bias; const float* gn_gamma; const float* gn_beta;
     int32_t gn_act;
     const float* raw_x1; const float* raw_x2; int32_t raw_C1, raw_C2;
+    /* (r06, tile 40) f32 weights of the fused GroupNorm + 3x3 conv with a TINY output width (N <= 4: the denoiser's output head,
+       pyunet.py:775-803): [Cin / 32][9 taps][N][32 channels] floats; B is unused.  Grown at the struct's END (FridoOp union: 512 B). */
+    const float* w_f32;
 } FridoGemm;
 
 /* GroupNorm statistics (32 groups, biased variance, fp32) over a virtual channel concat of two

@@ -1066,6 +1066,40 @@ def test_gn_conv_fused(case):
 
 
 @pytest.mark.gate
+@pytest.mark.parametrize("W,C,N,B", [(64, 192, 3, 2), (32, 192, 4, 3), (16, 96, 3, 2), (64, 32, 4, 1), (32, 960, 3, 1)])
+def test_gn_conv_tiny_output_head(W, C, N, B):
+    """(r06) csrc/convgn.hip conv3x3_gn_tiny_kernel (FridoGemm tile 40): the denoiser's eps head  conv3x3(SiLU(GroupNorm32(h)))  to 3 / 4
+    channels (pyunet.py:775-803) as ONE launch on the f32 VALU -- against F.group_norm -> F.silu -> F.conv2d in fp32 (bound 5e-6: plain f32
+    products and sums, no operand planes), and against the MFMA path it replaces (gn_apply + two-plane conv) on the same input.  64 / 32 /
+    16-wide planes (4 / 8 / 16 image rows per 256-pixel tile), 1, 3, 6 and 30 channel chunks, odd batch; zero padding on every edge."""
+    from frido_amd.builder import ACT_SILU
+    H = W
+    HW, M = H * W, B * H * W
+    x = _t("tn:x", B, HW, C) * 1.5 + 0.3
+    w, bi = 1 + 0.1 * _t("tn:gw", C), 0.1 * _t("tn:gb", C)
+    wc, bc = _t("tn:wc", N, C, 3, 3) / np.sqrt(9 * C), _t("tn:bc", N)
+    b = _builder(2, {"n.weight": w.cuda(), "n.bias": bi.cuda(), "c.weight": wc.cuda(), "c.bias": bc.cuda()})
+    f1 = b.f32(M, C)
+    f1.view().copy_(x.view(M, C).cuda())
+    assert b.gn_conv_tiny_ok(f1, B, H, W, N)
+    out = b.f32_strict(M, N)
+    out.view().fill_(float("nan"))
+    b.gn_conv_tiny(f1, B, H, W, "n", 1e-5, "c", out)
+    st = b.prog.ops[-1][1]
+    assert st.tile == 40 and st.gn_x1 and st.w_f32 and not st.A and not st.B
+    a_ref, _ = b.groupnorm(f1, None, B, HW, "n", 1e-5, act=ACT_SILU)
+    old = b.conv(a_ref, B, H, W, "c", out="f32_strict")
+    _run(b)
+    xn = x.view(B, H, W, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.silu(F.group_norm(xn, 32, w, bi, 1e-5)), wc, bc, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    got = out.view().cpu()
+    assert bool(torch.isfinite(got).all()) and _relerr(got, ref) < 5e-6, (W, C, N)
+    assert _relerr(old.view().cpu(), ref) < _tol(2)                  # the replaced path on the same input (its own bound)
+    # not applicable: more than 4 output channels, a bf16-mode builder, a plane that is no multiple of 256 pixels
+    assert not b.gn_conv_tiny_ok(f1, B, H, W, 8) and not _builder(1, {}).gn_conv_tiny_ok(f1, B, H, W, N) and not b.gn_conv_tiny_ok(f1, B, 8, 8, N)
+
+
+@pytest.mark.gate
 @pytest.mark.parametrize("W,C1,C2,Cout_prev,splitk,spade,resid,dead,B", [(16, 576, 0, 576, 4, False, False, False, 16), (8, 960, 0, 960, 8, True, True, False, 16),
                                                                          (16, 384, 192, 384, 3, False, True, False, 16), (8, 960, 0, 960, 5, False, False, True, 16),
                                                                          # r05: the shapes of BASELINE config 3 at its batch (CFG: 64 rows): 8 x 8 x 576 and 4 x 4 x 960

@@ -158,3 +158,28 @@ def test_gap_analysis_sampling_loop_window(tmp_path):
     loop = json.loads(out.stdout)["sampling_loop"]
     assert loop["forwards"] == 4 and loop["gemm_family_launches"] == 8 and loop["kernels_per_forward"] == 4.0
     assert abs(loop["gemm_family_ms_per_forward"] - 0.15) < 1e-9 and abs(loop["forward_ms_wall"] - 0.158375) < 1e-9
+
+
+def test_inflight_audit_flags_a_touched_destination_and_guards_the_build(tmp_path):
+    """(r06) tools/asm_inflight_check.py: between a hand-issued `global_load_dwordx4 vD` and the `s_waitcnt vmcnt` that covers it nothing may
+    read or write vD (conv3x3_gn_kernel rests on the compiler not splitting such a live range).  The audit exits non-zero on a hazard AND when
+    it sees no hand-issued load at all; `make -C frido_amd/csrc` runs it on both builds (a violation fails the build), checked here too."""
+    import subprocess
+    import sys
+    tool = os.path.join(REPO, "tools", "asm_inflight_check.py")
+    clean = ["_ZN12_GLOBAL__N_117conv3x3_gn_kernelILi256ELb0ELb0EEEv9FridoGemm:", "\tglobal_load_dwordx4 v[10:13], v[2:3], off", "\tv_add_u32_e32 v20, v21, v22",
+             "\ts_waitcnt vmcnt(0)", "\tv_add_f32_e32 v30, v10, v11", "\ts_endpgm", ".Lfunc_end0:"]
+    hazard = clean[:2] + ["\tv_mov_b32_e32 v40, v11"] + clean[2:]                 # a copy of an in-flight register: stale data
+    empty = [clean[0], "\tv_add_u32_e32 v20, v21, v22", "\ts_endpgm", ".Lfunc_end0:"]
+    for name, lines, rc in (("clean", clean, 0), ("hazard", hazard, 1), ("empty", empty, 1)):
+        f = tmp_path / f"{name}.s"
+        f.write_text("\n".join(lines) + "\n")
+        out = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+        assert out.returncode == rc, (name, out.stdout, out.stderr)
+    assert "v_mov_b32_e32 v40, v11" in subprocess.run([sys.executable, tool, str(tmp_path / "hazard.s")], capture_output=True, text=True).stdout
+    csrc = os.path.join(REPO, "frido_amd", "csrc")
+    if os.path.exists(os.path.join(csrc, "..", "libfrido_hip.so")) and os.path.exists("/opt/rocm/bin/hipcc"):
+        mk = subprocess.run(["make", "-C", csrc, "audit"], capture_output=True, text=True, env=dict(os.environ, PATH=os.environ.get("PATH", "") + ":/opt/rocm/bin"))
+        assert mk.returncode == 0, mk.stdout[-2000:] + mk.stderr[-2000:]
+        log = open(os.path.join(csrc, ".audit_f16.log")).read()
+        assert log.count("0 instructions touching an in-flight destination") == 8          # all eight instantiations of the fused kernel

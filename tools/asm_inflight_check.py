@@ -6,6 +6,8 @@ statement is over, so a live-range split / spill it places in that window would 
 import re
 import sys
 
+if len(sys.argv) < 2:
+    sys.exit(__doc__)
 src = open(sys.argv[1]).read().splitlines()
 CARRY = len(sys.argv) > 2 and sys.argv[2] == "carry"
 fn = None
@@ -79,3 +81,7 @@ for fn, (n, b) in stats.items():
     print(f"{fn[:90]}: {n} hand-issued loads, {b} instructions touching an in-flight destination")
 for fn, ln, code, (l0, c0) in bad[:20]:
     print(f"  line {ln}: {code}    <- in flight since line {l0}: {c0}")
+# exit status (r06: `make -C frido_amd/csrc audit`, part of `all`, and tests/test_host.py run this on every build): non-zero when a hazard
+# was found, or when no hand-issued load was seen at all (the audit would then be looking at the wrong thing)
+if bad or not stats or any(n == 0 for n, _ in stats.values()):
+    sys.exit(1)
