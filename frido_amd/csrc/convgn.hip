@@ -537,9 +537,11 @@ int launch_convgn_bm(const FridoGemm& d, hipStream_t s) {
 //   * plain f32 accumulation (exact products, 24-bit sums): at least as accurate as the two-plane path it replaces.
 // 65536 x 192 -> 3: 340 MFLOP, 50 MB read once -> HBM / VALU balanced at ~15 us.
 template <int NO>
-__global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d, const float* __restrict__ wq) {      // wq = d.w_f32 as a noalias argument: wave-uniform loads from it become s_load
-    constexpr int NT = 256, SS = 36, MAXSLOTS = 396, MAXC = 960;      // SS: floats per patch slot (32 channels + 4 pad)
-    constexpr int NRD = (MAXSLOTS * 4 + NT - 1) / NT;                  // staging rounds per chunk (8-channel units per thread): 7
+__global__ __launch_bounds__(512) void conv3x3_gn_tiny_kernel(const FridoGemm d, const float* __restrict__ wq) {      // wq = d.w_f32
+    // 256 pixels per workgroup on 512 threads: thread t and t + 256 own the SAME pixel and split a chunk's 32 channels 16 / 16 -- the
+    // launch is only 65536 pixels = 1024 waves of one-pixel-per-lane work, one wave per SIMD; the channel split makes it two
+    constexpr int TP = 256, NT = 512, SS = 36, MAXSLOTS = 396, MAXC = 960;      // SS: floats per patch slot (32 channels + 4 pad)
+    constexpr int NRD = (MAXSLOTS * 4 + NT - 1) / NT;                  // staging rounds per chunk (8-channel units per thread): 4
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* const patch = reinterpret_cast<float*>(smem);               // [MAXSLOTS][SS]
     float* const tab_sc = patch + MAXSLOTS * SS;
@@ -547,8 +549,8 @@ __global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d,
     float* const wl = tab_sh + MAXC;                                    // this chunk's weights [9 taps][128] (NO x 32 used)
     const int t = threadIdx.x;
     const int W = d.Ws, H = d.Hs, HW = H * W;
-    const int R = NT / W, PW = W + 2, PS = (R + 2) * PW;
-    const int m0 = (int)blockIdx.x * NT;
+    const int R = TP / W, PW = W + 2, PS = (R + 2) * PW;
+    const int m0 = (int)blockIdx.x * TP;
     const int img = m0 / HW, y0 = (m0 - img * HW) / W;
     const int C = d.gn_C1;
     const float* __restrict__ x1 = d.gn_x1;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d,
         float* s_rstd = s_mean + 64;
         const int cpg = C / d.gn_groups;
         double* s_part = reinterpret_cast<double*>(smem + 1024);
-        {
+        if (t < 256) {
             const int g = t & 31, l8 = t >> 5;
             double s = 0.0, q = 0.0;
             if (g < d.gn_groups) {
@@ -597,12 +599,12 @@ __global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d,
         __syncthreads();
     }
 
-    // ---- staging geometry: unit (round r) = patch slot r * 64 + (t >> 2), channels (t & 3) * 8 of the chunk ----
+    // ---- staging geometry: unit (round r) = patch slot r * 128 + (t >> 2), channels (t & 3) * 8 of the chunk ----
     const int cu = (t & 3) * 8;
     int pix[NRD];                                       // global pixel, -1: halo (zeros), -2: beyond the patch
 #pragma unroll
     for (int r = 0; r < NRD; ++r) {
-        const int slot = r * 64 + (t >> 2);
+        const int slot = r * 128 + (t >> 2);
         const int pr = slot / PW, px = slot - pr * PW;
         const int y = y0 + pr - 1, x = px - 1;
         pix[r] = slot >= PS ? -2 : ((y >= 0 && y < H && x >= 0 && x < W) ? img * HW + y * W + x : -1);
@@ -635,47 +637,47 @@ __global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d,
                     if (do_silu) y[e] = silu_f(y[e]);
                 }
             }
-            float* dst = patch + (r * 64 + (t >> 2)) * SS + cu;
+            float* dst = patch + (r * 128 + (t >> 2)) * SS + cu;
             *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
             *reinterpret_cast<float4*>(dst + 4) = make_float4(y[4], y[5], y[6], y[7]);
         }
     };
 
     // ---- this thread's output pixel: centre slot in the patch ----
-    const int prow = t / W, pcol = t - prow * W;
+    const int pxl = t & 255, half = t >> 8;               // this thread's pixel of the tile and its 16-channel half of every chunk
+    const int prow = pxl / W, pcol = pxl - prow * W;
     const int sc0 = (prow + 1) * PW + (pcol + 1);
-    float acc[NO];
+    float acc[NO][2];                                    // two independent chains per output: the FMA latency, not its rate, paced one chain
 #pragma unroll
-    for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+    for (int n = 0; n < NO; ++n) acc[n][0] = acc[n][1] = 0.f;
     const int nch = C >> 5;
     load_chunk(0);
     park_chunk(0);
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
         if (c + 1 < nch) load_chunk(c + 1);              // in flight under this chunk's multiply
-        // One tap = NO x 32 weights, the same for every pixel: lane l of a wave fetches weights l and 64 + l of the tap from LDS (two
-        // conflict-free ds_read_b32) and every FMA takes its weight out of those two registers with v_readlane_b32 -> SGPR operand.  (Tried
-        // first: s_load_dwordx16 from global -- the 20-KB weight set thrashes the scalar cache, 97 us per launch; 24 broadcast ds_read_b128
-        // per tap would make the launch LDS-bound at ~23 us.)  NOT unrolled over taps: registers.
+        // One tap = NO x 16 weights per channel half, the same for every pixel: lane l < NO * 16 of a wave fetches weight (n = l / 16,
+        // channel 16 half + l % 16) of the tap from LDS (one conflict-free ds_read_b32) and every FMA takes its weight out of that register
+        // with v_readlane_b32 -> SGPR operand.  (Tried first: s_load_dwordx16 from global -- the 20-KB weight set thrashes the scalar cache,
+        // 97 us per launch; 24 broadcast ds_read_b128 per tap would make the launch LDS-bound.)  NOT unrolled over taps: registers.
         const int lane = t & 63;
+        const int wsel = (lane >> 4) * 32 + half * 16 + (lane & 15);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            const float w0 = wl[tap * 128 + lane], w1 = wl[tap * 128 + 64 + lane];
-            const float* ap = patch + (sc0 + (tap / 3 - 1) * PW + (tap % 3 - 1)) * SS;
-            float a[32];
+            const float w0 = wl[tap * 128 + (wsel & 127)];
+            const float* ap = patch + (sc0 + (tap / 3 - 1) * PW + (tap % 3 - 1)) * SS + half * 16;
+            float a[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(ap + 4 * q);
                 a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
             }
 #pragma unroll
-            for (int e = 0; e < 32; ++e)
+            for (int e = 0; e < 16; ++e)
 #pragma unroll
                 for (int n = 0; n < NO; ++n) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int idx = n * 32 + e;
-                    const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idx < 64 ? w0 : w1), idx & 63));
-                    acc[n] = fmaf(a[e], wv, acc[n]);
+                    const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w0), n * 16 + e));
+                    acc[n][e & 1] = fmaf(a[e], wv, acc[n][e & 1]);
                 }
         }
         __syncthreads();                                 // every thread is done reading the patch
@@ -684,11 +686,18 @@ __global__ __launch_bounds__(256) void conv3x3_gn_tiny_kernel(const FridoGemm d,
             __syncthreads();
         }
     }
-    const int m = m0 + t;
-    if (m < d.M) {
+    // the two channel halves of a pixel -> one: the upper half parks its sums in LDS (the patch is dead), the lower half adds and stores
+    float* red = patch + pxl * 4;
+    if (half == 1) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) red[n] = acc[n][0] + acc[n][1];
+    }
+    __syncthreads();
+    const int m = m0 + pxl;
+    if (half == 0 && m < d.M) {
 #pragma unroll
         for (int n = 0; n < NO; ++n)
-            if (n < d.N) d.out_f32[(int64_t)m * d.ldo + n] = d.alpha * acc[n] + (d.bias ? d.bias[n] : 0.f);
+            if (n < d.N) d.out_f32[(int64_t)m * d.ldo + n] = d.alpha * ((acc[n][0] + acc[n][1]) + red[n]) + (d.bias ? d.bias[n] : 0.f);
     }
 }
 
@@ -713,8 +722,8 @@ int frido_launch_convgn_tiny(const FridoGemm& d, hipStream_t s) {
         frido_set_error("igemm: tile 40 (fused GroupNorm + 3x3 conv with 3 / 4 output channels) does not apply to this descriptor");
         return FRIDO_EINVAL;
     }
-    if (d.N == 3) hipLaunchKernelGGL((conv3x3_gn_tiny_kernel<3>), dim3(d.M / 256), dim3(256), CG_TINY_SMEM, s, d, d.w_f32);
-    else hipLaunchKernelGGL((conv3x3_gn_tiny_kernel<4>), dim3(d.M / 256), dim3(256), CG_TINY_SMEM, s, d, d.w_f32);
+    if (d.N == 3) hipLaunchKernelGGL((conv3x3_gn_tiny_kernel<3>), dim3(d.M / 256), dim3(512), CG_TINY_SMEM, s, d, d.w_f32);
+    else hipLaunchKernelGGL((conv3x3_gn_tiny_kernel<4>), dim3(d.M / 256), dim3(512), CG_TINY_SMEM, s, d, d.w_f32);
     return frido_check_launch("conv3x3_gn_tiny");
 }
 

@@ -321,7 +321,7 @@ class SamplerEngine:
                 multi.keep = [plan]
                 self.graphs[kkey] = multi.capture(sp)
             gk = self.graphs[kkey]
-        needs_host = lambda i: (n - i - 1) % log_every_t == 0 or i == n - 1          # what _log does at step i without callbacks
+        needs_host = lambda i: (n - i - 1) % log_every_t == 0 or i == 0              # when _log touches the state at step i (index = n - i - 1) without callbacks
         i = 0
         while i < n:
             if gk is not None and i + K <= n and not any(needs_host(j) for j in range(i, i + K - 1)):
