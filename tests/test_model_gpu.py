@@ -491,20 +491,21 @@ def test_sampler_philox_graph_replay_is_deterministic_and_shard_invariant():
 def test_ddim_several_steps_per_captured_graph_is_bit_identical(noise, monkeypatch):
     """(r06) runtime.GRAPH_STEPS = K: the step body K times in one captured graph, replayed wherever no host access (log / callback) falls
     between the steps.  Same kernels, same order, same device step counter: latents AND logged intermediates must equal the one-graph-per-
-    step run bit for bit -- with S = 11 and log_every_t = 4 both forms (4-step replays and single steps around the logged ones) are mixed."""
+    step run bit for bit -- with S = 10 and log_every_t = 5 both forms (4-step replays and single steps around the logged ones) are mixed."""
     from frido.models.diffusion.ddim import DDIMSampler
     from frido_amd import runtime
     from frido_amd.synth import seeded_normal
     c = torch.from_numpy(seeded_normal("gs:c", (2, 5, 64))).cuda()
-    tape = seeded_normal("gs:noise", (2 * 6 * 256 + 11 * 2 * 3 * 256 + 11 * 2 * 6 * 256,))
+    tape = seeded_normal("gs:noise", (2 * 6 * 256 + 10 * 2 * 3 * 256 + 10 * 2 * 6 * 256,))
     outs = []
     for K in (1, 4):
         monkeypatch.setattr(runtime, "GRAPH_STEPS", K)
         model = _frido(UNET_SMALL, VQ_SMALL)
-        z, inter = DDIMSampler(model).sample(S=11, batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=1.0, verbose=False,
-                                             log_every_t=4, noise="philox" if noise == "philox" else _Tape(tape), seed=5)
+        z, inter = DDIMSampler(model).sample(S=10, batch_size=2, shape=(6, 16, 16), conditioning=c, num_stage=2, eta=1.0, verbose=False,
+                                             log_every_t=5, noise="philox" if noise == "philox" else _Tape(tape), seed=5)
         eng = next(iter(model.model.diffusion_model.runtime()._sampler_engines.values()))
         assert any(isinstance(k[-1], str) and k[-1] == "x4" for k in eng.graphs) == (K == 4)
+        assert getattr(eng, "multi_step_launches", 0) == (4 if K == 4 else 0)          # two 4-step replays per stage (steps 1-4 and 5-8), two stages
         outs.append((z.cpu(), [t.cpu() for t in inter["x_inter"]], [t.cpu() for t in inter["pred_x0"]]))
     (z1, xi1, p1), (z4, xi4, p4) = outs
     assert torch.equal(z1, z4) and len(xi1) == len(xi4) and all(torch.equal(a, b) for a, b in zip(xi1 + p1, xi4 + p4))

@@ -2,7 +2,7 @@
 # Round profile collection on the GPU box (writes summaries under gpurun_out/; copy the ones to keep into profiles/):
 #   kernel-trace stats + gap analysis of bench.py, PMC passes (SQ / GRBM / TCC, each in its own run) over
 #   tools/profile_forward.py, and an rocm-smi clock / power log taken while bench.py runs.
-TAG=${1:-r05_x3}
+TAG=${1:-r06_x3}
 PREC=${2:-bf16x3}      # arithmetic profiled: bf16x3 (the parity / headline mode) or bf16
 ONLY=${3:-all}         # all | trace (kernel trace + gap analysis of the bench command only, on the pinned tiles)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
