@@ -137,7 +137,31 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
     // MALL / HBM for 18.6 MB of operands (tools/_pmc_smallm.sh).
     const int kz = xcd_item(nb) / nb;                          // (KG = 2 launches have gridDim.z == 1: kz = 0)
     const int bid = xcd_item(nb) - kz * nb;
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // (r06) COLUMN PANELS (FridoGemm.flags bit 27): with many tile columns an XCD's 64 concurrent workgroups cover a few tile rows x ALL
+    // columns, i.e. the whole weight matrix -- beyond its 4-MB L2 (GEGLU projection 16384 x 3072 x 384: 4.7 MB of weights + the rows'
+    // activations), so every group of tile rows streams the weights from MALL again: PMC (profiles/r06_pmc_l2_by_instance_*.json) L2 hit rate
+    // 81 %, 162 MB fetched per launch for 30 MB of operands.  Tiles are therefore walked panel by panel -- P columns x all rows, P = 8, halved while its weight
+    // panel exceeds 3 MB (64 concurrent workgroups = 8 rows x 8 columns minimise rows + columns) -- so the concurrent set is a block of rows x P columns: the panel stays L2-resident
+    // while the rows stream through once.  Pure re-ordering of independent tiles: results unchanged bit for bit.
+    if ((d.flags >> 27) & 1) {
+        const int colbytes = BN * (d.K + d.K2) * 2 * NS;
+        int P = 8;
+        while (P > 1 && P * colbytes > (3 << 20)) P >>= 1;
+        if (P > 1 && tiles_n > P) {
+            const int full = tiles_n / P, per_panel = tiles_m * P;
+            const int p = bid / per_panel;
+            if (p < full) {
+                const int r = bid - p * per_panel;
+                tm = r / P;
+                tn = p * P + (r - tm * P);
+            } else {
+                const int rem = tiles_n - full * P, r = bid - full * per_panel;
+                tm = r / rem;
+                tn = full * P + (r - tm * rem);
+            }
+        }
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     if constexpr (((FRIDO_ABLATE & 1024) || FRIDO_STAGGER_RT) && NW == 4) {
         const int id = ((int)blockIdx.y * (int)gridDim.z + (int)blockIdx.z) * (int)gridDim.x + (int)blockIdx.x;

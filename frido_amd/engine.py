@@ -25,6 +25,12 @@ STAGGER_MODE = int(os.environ.get("FRIDO_STAGGER_MODE", "0"))        # 0: dispat
 STAGGER_8W = int(os.environ.get("FRIDO_STAGGER_8W", "0"))            # 1: the one-workgroup-per-CU kernels too (odd XCDs start late; igemm_shared.h)
 GEMM_FLAGS |= (((int(round(STAGGER_US * 4)) & 255) << 8) | (((STAGGER_MIN_WG // 64) & 255) << 16) | ((STAGGER_MODE & 3) << 24)
                | ((STAGGER_8W & 1) << 26))
+# (r06) column-panel tile order of the ring GEMM kernel (igemm.hip; FridoGemm.flags bit 27): keeps a launch's weight panel L2-resident per XCD.
+# Built on a PMC finding (the GEGLU projection fetches 162 MB per launch for 30 MB of operands, L2 hit rate 81 %: profiles/r06_pmc_l2_by_instance_*.json);
+# measured: -5 % per GEGLU launch in the back-to-back microbenchmark, +0.06 % end to end (three interleaved pairs, profiles/r06_panels_*.txt) -- the L2
+# misses are not what paces these k-loops.  OFF by default: the r05 tile order stays the validated one.
+GEMM_PANELS = os.environ.get("FRIDO_GEMM_PANELS", "0") != "0"
+GEMM_FLAGS |= (1 << 27) if GEMM_PANELS else 0
 BF16X3 = 2   # nsplit: hi + residual plane, 3 MFMAs per product (≈ fp32 accuracy)
 BF16 = 1     # nsplit: plain bf16 operands
 

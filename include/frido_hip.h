@@ -139,7 +139,10 @@ typedef struct FridoGemm {
                                    bits 8..15 / 16..23 / 24..25 (r05 experiment, honoured only by -DFRIDO_STAGGER_RT=1 builds of igemm.hip,
                                    results unchanged): start delay in quarter microseconds of the workgroups with dispatch ids 256..511 of a
                                    two-per-CU tile / smallest grid it applies to in units of 64 workgroups (0 = 768) / which workgroups wait; bit 26: the
-                                   one-workgroup-per-CU kernels too (odd XCDs of the first 256 workgroups wait) */
+                                   one-workgroup-per-CU kernels too (odd XCDs of the first 256 workgroups wait);
+                                   bit 27 (r06): the ring kernel walks its output tiles in COLUMN PANELS (P = 8 columns x all rows, P halved while the weight panel
+                                   exceeds 3 MB) instead of row-major, so that an XCD's concurrent workgroups share an L2-resident weight panel;
+                                   a pure re-ordering of independent tiles, results unchanged */
     /* optional uint8 image output (r04: the output path of scripts/sample_diffusion.py fused into the decoder's last conv --
        the all-gather and the NPZ / PNG writers then move uint8): out_u8[row * ldu8 + n] for n < N, NHWC.  u8_mode 1 =
        custom_to_np (sample_diffusion.py:115-121): ((x + 1) * 127.5) clamped to [0, 255], truncated; 2 = custom_to_pil

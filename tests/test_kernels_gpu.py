@@ -659,6 +659,32 @@ def test_gemm_k_split_inside_the_workgroup(tile, K):
             _run(b)
 
 
+@pytest.mark.gate
+@pytest.mark.parametrize("tile,N,K", [(2, 3072, 384), (3, 1216, 960), (1, 1408, 2304), (7, 1024, 384), (18, 2112, 96)])
+def test_gemm_column_panel_tile_order_is_a_pure_reordering(tile, N, K):
+    """(r06) FridoGemm.flags bit 27: the ring kernel walks its output tiles panel by panel (P columns x all rows, P = 8, halved while the weight panel
+    exceeds 3 MB: 8 / 8 / 4 / 8 / 8 here) instead of row-major, so an XCD's concurrent workgroups share an L2-resident weight
+    panel.  Independent tiles in another order: the output must equal the row-major run BIT FOR BIT (and the fp32 reference to the usual
+    bound) -- full panels plus a ragged last one (19 / 11 / 8 / 11 tile columns), ragged M, GEGLU and plain epilogues."""
+    M = 700
+    a, w, bias = _t("pa", M, K), _t("pw", N, K) / np.sqrt(K), _t("pb", N)
+    outs = []
+    for panels in (0, 1):
+        b = _builder(2, {"w.weight": w.cuda(), "w.bias": bias.cuda()})
+        ad = a.cuda()
+        a_op = b.pack(ad.data_ptr(), 1, M, K, 0, K)
+        o = b.linear_geglu(a_op, "w") if tile == 2 else b.linear(a_op, "w", out="op")
+        st = b.prog.ops[-1][1]
+        st.tile = tile
+        st.flags = (st.flags & ~(1 << 27)) | (panels << 27)
+        _run(b)
+        outs.append(o.to_f32().cpu())
+    assert torch.equal(outs[0], outs[1])
+    y = a @ w.t() + bias
+    ref = y[:, :N // 2] * F.gelu(y[:, N // 2:]) if tile == 2 else y
+    assert _relerr(outs[1][:, :ref.shape[1]], ref) < _tol(2)
+
+
 @pytest.mark.parametrize("K", [64, 128, 192, 448])
 @pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 16, 17])
 def test_pipelined_loop_short_k(tile, K):
