@@ -23,6 +23,9 @@ python $R/tools/pmc_traffic.py /tmp/pmc_fetch > /tmp/tr_f.json 2>/dev/null
 mkdir -p /tmp/pmc_both; cp -r /tmp/pmc_fetch /tmp/pmc_both/f; cp -r /tmp/pmc_write /tmp/pmc_both/w
 python $R/tools/pmc_traffic.py /tmp/pmc_both > $OUT/${TAG}_pmc_traffic.json 2> $OUT/${TAG}_pmc_traffic.err
 tail -3 /tmp/pmc_sq.log > $OUT/${TAG}_pmc_logs.txt; tail -3 /tmp/pmc_grbm.log >> $OUT/${TAG}_pmc_logs.txt
+# (r06) L2 behaviour per kernel INSTANCE (template instantiation x grid): hit rate and bytes fetched from MALL / HBM per launch
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d /tmp/pmc_l2 -- python $R/tools/profile_forward.py --precision $PREC > /tmp/pmc_l2.log 2>&1
+python $R/tools/pmc_instances.py /tmp/pmc_l2 /tmp/pmc_grbm --top 45 > $OUT/${TAG}_pmc_l2_instances.json 2> $OUT/${TAG}_pmc_l2_instances.err
 fi
 # ---- kernel trace of the bench command (the headline workload only: the other configs of the default line stay out of the window) ----
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktrace -- python $R/bench.py --precision $PREC --steps 1 --warmup 1 --no-cpu-baseline --no-bf16-extra --no-other-configs > $OUT/${TAG}_bench_under_trace.json 2> /tmp/ktrace.log
