@@ -15,6 +15,7 @@ installed) on synthetic vocabularies written by the test; the real files have ne
 import gzip
 import html
 import os
+import re
 import unicodedata
 from functools import lru_cache
 
@@ -58,10 +59,23 @@ class WordPieceTokenizer:
             if name not in self.vocab:
                 raise ValueError(f"{vocab_file}: special token {name} is missing")
         self.unk, self.cls, self.sep, self.pad = (self.vocab[t] for t in (unk, cls, sep, pad))
-        self.special = {unk, cls, sep, pad, "[MASK]"}
+        # (r06, advisor) "[MASK]" is special only where the vocabulary holds it (a vocab without it used to raise KeyError on a caption containing the string)
+        self.special = {t for t in (unk, cls, sep, pad, "[MASK]") if t in self.vocab}
+        # HF's added-token matching extracts a special token ANYWHERE in the text ("a[SEP]b", "cats [SEP]."), not only as a whitespace-separated
+        # word: the text is split on the special strings first (longest first), the pieces in between go through the basic tokenizer
+        self._special_re = re.compile("(" + "|".join(re.escape(t) for t in sorted(self.special, key=len, reverse=True)) + ")")
         self.max_chars = max_chars_per_word
 
     def _basic(self, text):
+        words = []
+        for piece in self._special_re.split(text):
+            if piece in self.special:
+                words.append(piece)
+            elif piece:
+                words += self._basic_plain(piece)
+        return words
+
+    def _basic_plain(self, text):
         out = []
         for ch in text:                                                     # clean: drop NUL / U+FFFD / controls, whitespace -> " "
             cp = ord(ch)
@@ -73,9 +87,6 @@ class WordPieceTokenizer:
                 out.append(" " if _is_whitespace(ch) else ch)
         words = []
         for tok in "".join(out).split():
-            if tok in self.special:
-                words.append(tok)
-                continue
             if self.lower:
                 tok = tok.lower()
                 tok = "".join(c for c in unicodedata.normalize("NFD", tok) if unicodedata.category(c) != "Mn")
@@ -154,7 +165,9 @@ class ClipBPETokenizer:
         opener = gzip.open if str(bpe_path).endswith(".gz") else open
         with opener(bpe_path, "rt", encoding="utf-8") as f:
             lines = f.read().split("\n")
-        if lines and (lines[0].startswith("#") or lines[0].startswith('"')):     # "#version: 0.2" / the OpenAI file's header line
+        # (r06, advisor) only a REAL header is dropped -- a first line that says "#version": HF's "#version: 0.2", the OpenAI file's '"bpe_simple_vocab_16e6.txt#version: 0.2';
+        # a header-less merges file whose first merge happens to start with '#' or '"' keeps it
+        if lines and "#version" in lines[0]:
             lines = lines[1:]
         merges = [tuple(l.split()) for l in lines if len(l.split()) == 2]
         if n_merges is not None:

@@ -179,3 +179,32 @@ def test_clip_bpe_matches_hf_on_random_ascii_captions(clip_files):
         assert [mine.sot] + mine.encode(caption) + [mine.eot] == hf(caption)["input_ids"], repr(caption)
 
     check()
+
+
+def test_wordpiece_special_tokens_anywhere_like_bert_tokenizer_fast(bert_vocab, tmp_path):
+    """(r06, advisor) HF's added-token matching pulls a special token out of the text wherever it stands -- "a[SEP]b", "cats [SEP]." -- not
+    only as a whitespace-separated word; a vocabulary WITHOUT [MASK] must treat the string as ordinary text instead of raising KeyError."""
+    from transformers import BertTokenizerFast
+    hf = BertTokenizerFast(vocab=bert_vocab, do_lower_case=True)
+    if hf.vocab_size != len(BERT_VOCAB):
+        pytest.skip("this transformers version did not load the synthetic vocabulary")
+    mine = WordPieceTokenizer(bert_vocab)
+    for c in ("a[SEP]b", "cats [SEP].", "[CLS]a cat[PAD][PAD] on", "a [UNK]cat", "x[SEP][SEP]y [SEP]"):
+        want = hf(c, add_special_tokens=True)["input_ids"]
+        assert [mine.cls] + mine.encode(c) + [mine.sep] == want, c
+    nomask = tmp_path / "vocab_nomask.txt"
+    nomask.write_text("\n".join(t for t in BERT_VOCAB if t != "[MASK]") + "\n", encoding="utf-8")
+    tk = WordPieceTokenizer(str(nomask))
+    assert "[MASK]" not in tk.special and isinstance(tk.encode("a [MASK] cat"), list)       # ordinary text: "[", "mask", "]" pieces or [UNK]s, no KeyError
+
+
+def test_clip_merges_file_without_a_header_keeps_its_first_merge(tmp_path):
+    """(r06, advisor) only a real header line is dropped ("#version: ..." / the OpenAI file's first line): a header-less merges file whose first
+    merge starts with '#' or '"' keeps that merge."""
+    from frido_amd.tokenizers import ClipBPETokenizer
+    body = ['# a', 'a b</w>', '" x</w>']
+    for header, n in ((None, 3), ("#version: 0.2", 3), ('"bpe_simple_vocab_16e6.txt#version: 0.2', 3)):
+        p = tmp_path / f"m_{n}_{bool(header)}_{len(header or '')}.txt"
+        p.write_text("\n".join(([header] if header else []) + body) + "\n", encoding="utf-8")
+        tk = ClipBPETokenizer(str(p), n_merges=None)
+        assert len(tk.ranks) == n and ("#", "a") in tk.ranks, header
