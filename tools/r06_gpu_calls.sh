@@ -71,4 +71,25 @@ call3() {
   done
 }
 
-"${1:?call1 | call2 | call3}"
+call4() {
+  # Round-6 GPU call 4 (second session): scalar-base staging loads of the fused GroupNorm + conv kernel and the pass-major MFMA order of the
+  # plain-loop k-step (FRIDO_SLAB0; tools/build_variants.sh head "" slab0 -DFRIDO_SLAB0=0 slab1 -DFRIDO_SLAB0=1 slab2 -DFRIDO_SLAB0=2 beforehand):
+  # gate on the new default build, per-launch times of the affected kernels per variant, interleaved end-to-end A/B on one set of pinned tiles.
+  R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; OUT=$R/gpurun_out; mkdir -p $OUT
+  ( time python -m pytest tests -m "gpu and gate" -q -x --durations=5 > $OUT/r06c4_gate.log 2>&1 ) 2> $OUT/r06c4_gate.time; tail -5 $OUT/r06c4_gate.log; cat $OUT/r06c4_gate.time
+  ( for v in head slab0 slab1 slab2; do
+      export FRIDO_LIB=$R/tools/ablate/libfrido_$v.so
+      echo "== $v"
+      python tools/gnconv_bench.py 16 64 64 192 0 192 0 0 2>&1 | grep -E "fused.*total|^=="
+      python tools/gnconv_bench.py 16 64 64 192 0 192 1 0 2>&1 | grep -E "fused.*total|^=="
+      python tools/gnconv_bench.py 16 64 64 192 0 192 1 384 2>&1 | grep -E "fused.*total|^=="
+      python tools/gnconv_bench.py 16 32 32 384 0 384 0 0 2>&1 | grep -E "fused.*total|^=="
+      python tools/gemm_bench.py dense 16384 3072 384 2 2,19 2>&1 | grep -E "tile|rror"
+      python tools/gemm_bench.py dense 4096 4608 576 2 2,5 2>&1 | grep -E "tile|rror"
+    done ) > $OUT/r06_slab0_per_launch.txt 2>&1; cat $OUT/r06_slab0_per_launch.txt
+  unset FRIDO_LIB
+  ROUNDS=3 bash tools/ab.sh lib tools/ablate/libfrido_head.so tools/ablate/libfrido_slab0.so tools/ablate/libfrido_slab1.so tools/ablate/libfrido_slab2.so > $OUT/r06_slab0_end_to_end_ab.txt 2>&1
+  cat $OUT/r06_slab0_end_to_end_ab.txt
+}
+
+"${1:?call1 | call2 | call3 | call4}"
