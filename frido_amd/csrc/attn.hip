@@ -184,6 +184,19 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
         f32x4 acc[G];
 #pragma unroll
         for (int q = 0; q < G; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (r06) the stream form's residual / bias values of this lane's read-back slot go out WITH the V^T fragments: fetched where they are
+        // consumed (after the MFMAs and the LDS transpose) they put a second global round trip on every pass of this serial loop
+        float4 pre_r[CPL / 4], pre_b[CPL / 4];
+        const bool pre = d.out_act && oc < ng * 16;
+        if (pre) {
+            const int colp = tb * 16 + oc;
+            const int64_t rop = (int64_t)(row0 + orow) * d.ldr + colp;
+#pragma unroll
+            for (int i = 0; i < CPL / 4; ++i) {
+                if (d.bias) pre_b[i] = *reinterpret_cast<const float4*>(d.bias + colp + i * 4);
+                if (d.residual) pre_r[i] = load_act4(d.residual, rop + i * 4, d.act_bf16);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KP; ++ks)
             if (ks < nkp) {
@@ -211,17 +224,17 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
             const int sxor = SO_SWZ ? (orow & 7) << 2 : 0;      // 4-float chunk c of this row lives at chunk c ^ (row & 7)
             const int col = tb * 16 + oc;
             if (d.out_act) {                    // residual-stream form: O + bias + residual
-                const int64_t ro = (int64_t)(row0 + orow) * d.ldr + col, oo = (int64_t)(row0 + orow) * d.ld_act + col;
+                const int64_t oo = (int64_t)(row0 + orow) * d.ld_act + col;
                 float keep[CPL];                // (r03) the same values once more as an operand, when out_op is given as well
 #pragma unroll
                 for (int i = 0; i < CPL / 4; ++i) {
                     float4 v = *reinterpret_cast<const float4*>(srow + ((oc + i * 4) ^ sxor));
                     if (d.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(d.bias + col + i * 4);
+                        const float4 bb = pre_b[i];
                         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
                     }
                     if (d.residual) {
-                        const float4 rr = load_act4(d.residual, ro + i * 4, d.act_bf16);
+                        const float4 rr = pre_r[i];
                         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                     }
                     if (d.skip_act_store) {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                     for (int i = 0; i < CPL / 8; ++i) {
                         uint32_t h[8], l[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) split_op(keep[i * 8 + e], NS, h[e], l[e]);
+                        for (int e = 0; e < 8; e += 2) { split_op2(keep[i * 8 + e], keep[i * 8 + e + 1], NS, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
                         if (NS == 2) sat |= op_sat8(keep + i * 8);
                         *reinterpret_cast<uint4*>(dst + i * 8) =
                             make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                     const float4 s0 = *reinterpret_cast<const float4*>(srow + ((oc + i * 8) ^ sxor)), s1 = *reinterpret_cast<const float4*>(srow + ((oc + i * 8 + 4) ^ sxor));
                     const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) split_op(sv[e], NS, h[e], l[e]);
+                    for (int e = 0; e < 8; e += 2) { split_op2(sv[e], sv[e + 1], NS, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
                     if (NS == 2) sat |= op_sat8(sv);
                     *reinterpret_cast<uint4*>(dst + i * 8) =
                         make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
@@ -307,8 +320,26 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
         status_raise(false, wave == 0 && (lane & 3) == 0 && stat_bad(mean, rstd));
         // second pass over the values this lane parked in LDS
         frido_bf16* dst = d.ln_op + (int64_t)(row0 + orow) * d.ld_ln;
+        // (r06) the affine parameters of pass tb + G are fetched before pass tb's stores go out: the compiler cannot move a load above the
+        // stores of the previous pass, so every pass of this loop waited out its own L2 round trip
+        float4 nw[CPL / 8][2], nb[CPL / 8][2];
+        auto fetch_affine = [&](int tb) {
+            const int ng = t1 - tb < G ? t1 - tb : G;
+            if (tb >= t1 || oc >= ng * 16) return;
+#pragma unroll
+            for (int i = 0; i < CPL / 8; ++i) {
+                const int c = tb * 16 + oc + i * 8;
+                nw[i][0] = *reinterpret_cast<const float4*>(d.ln_w + c); nw[i][1] = *reinterpret_cast<const float4*>(d.ln_w + c + 4);
+                nb[i][0] = *reinterpret_cast<const float4*>(d.ln_b + c); nb[i][1] = *reinterpret_cast<const float4*>(d.ln_b + c + 4);
+            }
+        };
+        fetch_affine(t0);
         for (int tb = t0; tb < t1; tb += G) {
             const int ng = t1 - tb < G ? t1 - tb : G;
+            float4 cw[CPL / 8][2], cb[CPL / 8][2];
+#pragma unroll
+            for (int i = 0; i < CPL / 8; ++i) { cw[i][0] = nw[i][0]; cw[i][1] = nw[i][1]; cb[i][0] = nb[i][0]; cb[i][1] = nb[i][1]; }
+            fetch_affine(tb + G);
             if (oc >= ng * 16) continue;
             const int col = tb * 16 + oc;
 #pragma unroll
@@ -316,14 +347,14 @@ __global__ __launch_bounds__(NW * 64) void attn_small_kernel(const FridoAttnSmal
                 const int c = col + i * 8;
                 const float* xr = park + (((tb - t0) / G) * (CPL / 4) + i * 2) * 256;
                 const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 256);
-                const float4 w0 = *reinterpret_cast<const float4*>(d.ln_w + c), w1 = *reinterpret_cast<const float4*>(d.ln_w + c + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(d.ln_b + c), b1 = *reinterpret_cast<const float4*>(d.ln_b + c + 4);
+                const float4 w0 = cw[i][0], w1 = cw[i][1];
+                const float4 b0 = cb[i][0], b1 = cb[i][1];
                 const float y[8] = {(x0.x - mean) * rstd * w0.x + b0.x, (x0.y - mean) * rstd * w0.y + b0.y, (x0.z - mean) * rstd * w0.z + b0.z,
                                     (x0.w - mean) * rstd * w0.w + b0.w, (x1.x - mean) * rstd * w1.x + b1.x, (x1.y - mean) * rstd * w1.y + b1.y,
                                     (x1.z - mean) * rstd * w1.z + b1.z, (x1.w - mean) * rstd * w1.w + b1.w};
                 uint32_t h[8], l[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_op(y[e], NS, h[e], l[e]);
+                for (int e = 0; e < 8; e += 2) { split_op2(y[e], y[e + 1], NS, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
                 sat |= op_sat8(y);
                 *reinterpret_cast<uint4*>(dst + c) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 *reinterpret_cast<uint4*>(dst + d.ln_lo + c) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));

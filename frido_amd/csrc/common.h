@@ -64,6 +64,27 @@ __device__ __forceinline__ void split_op(float v, int ns, uint32_t& hi, uint32_t
         lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
     }
 }
+// (r06) two values at once, planes already PACKED (low half = a): on gfx950 the fp16 path is 2 x v_med3 + v_cvt_pk_f16_f32 + 2 x v_cvt_f32_f16 +
+// v_pk_add_f32 + v_cvt_pk_f16_f32 = 7 instructions per pair against 14 with split_op + shift / or packing.  Same roundings (RNE), same exact
+// residual: the same bits as split_op.
+typedef _Float16 frido_h2 __attribute__((ext_vector_type(2)));
+typedef float frido_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_op2(float a, float b, int ns, uint32_t& hi, uint32_t& lo) {
+    if (FRIDO_X3_F16 && ns == 2) {
+        frido_f2 v = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+        const frido_h2 h = __builtin_convertvector(v, frido_h2);
+        const frido_f2 r = v - __builtin_convertvector(h, frido_f2);
+        const frido_h2 l = __builtin_convertvector(r, frido_h2);
+        hi = __builtin_bit_cast(uint32_t, h);
+        lo = __builtin_bit_cast(uint32_t, l);
+    } else {
+        uint32_t h0, l0, h1, l1;
+        split_op(a, ns, h0, l0);
+        split_op(b, ns, h1, l1);
+        hi = h0 | (h1 << 16);
+        lo = l0 | (l1 << 16);
+    }
+}
 // ---- sticky status word (r05).  The library cannot throw from a kernel; instead every operand producer and every normalisation
 //      kernel ORs a bit into a per-translation-unit device word when it meets a value the arithmetic cannot represent, and
 //      frido_status_flags() (runtime.hip) ORs the words together for the host:
@@ -124,7 +145,17 @@ __device__ __forceinline__ f32x4 mfma_op(bf16x8 a, bf16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// (r06) x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of an IEEE division: the division was 11 of the ~24 VALU instructions per element of
+// every normalise + SiLU + split conversion (tools/cg_prof.py: that conversion is the top-of-step work the fused GroupNorm + conv kernel's
+// matrix pipe waits for; ISA count: 196 -> ~115 instructions per 8-channel unit).  One more ulp on a value that is split into two fp16
+// planes afterwards: 1e-7 relative, two orders below the parity bounds.  -DFRIDO_SILU_DIV=1 restores the division.
+#ifndef FRIDO_SILU_DIV
+#define FRIDO_SILU_DIV 0
+#endif
+__device__ __forceinline__ float silu_f(float v) {
+    if constexpr (FRIDO_SILU_DIV) return v / (1.0f + __expf(-v));
+    else return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): one rcp, one exp, six FMAs.  libm's erff costs ~3x as many
 // VALU cycles, and the GEGLU epilogue evaluates it 2e8 times per denoiser forward (it was VALU-, not store-bound).
 __device__ __forceinline__ float erf_fast(float x) {
@@ -156,7 +187,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void store_op4(frido_bf16* op, int64_t lo_off, int nsplit, int64_t idx, const float v[4]) {
     uint32_t h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_op(v[i], nsplit, h[i], l[i]);
+    for (int i = 0; i < 4; i += 2) { split_op2(v[i], v[i + 1], nsplit, h[i], l[i]); h[i + 1] = 0u; l[i + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
     uint2 ph = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     *reinterpret_cast<uint2*>(op + idx) = ph;
     if (nsplit == 2) {

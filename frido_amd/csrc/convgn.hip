@@ -32,6 +32,35 @@ namespace {
 #ifndef CG_ABLATE
 #define CG_ABLATE 0
 #endif
+// (r06) 1: the step barrier sits INSIDE the k-step, at the head of its last weight slab (see "mid-step barrier" in the kernel); 0: r04's
+// barrier at the top of every step.  Same MFMAs on the same operands in the same order: bit-identical results.
+#ifndef CG_MIDBAR
+#define CG_MIDBAR 0
+#endif
+// (r06) -DCG_PROF=1 (tools/cg_prof.py; never in the shipped build): every wave of the r04 loop form (CG_MIDBAR=0) sums, over its k-steps,
+// the shader cycles (s_memtime) it spends  [0] waiting for the step's weights (end of the previous step -> arrival at the barrier),
+// [1] inside the barrier, [2] on the weight DMA issue + staging (release -> first fragment address), [3] on fragment reads + MFMAs;
+// [4] = the whole loop, [5] = kernel start -> loop, [6] = epilogue.  Stamps sit where lgkmcnt is 0 anyway (an s_memtime is an SMEM read).
+#ifndef CG_PROF
+#define CG_PROF 0
+#endif
+// (r06) 1: PING-PONG.  The two waves of a SIMD (w and w + 4) run HALF A STEP APART: waves 0-3 own the tile's columns 0-95, waves 4-7 columns
+// 96-191 (so each group streams ITS OWN half of a step's weights and nobody else reads them), group X = waves 0-3 meets at the "A" barriers,
+// group Y at the "B" barriers in between; a group's own barrier is the top of its step (weight DMA issue, staging), the other group's
+// barrier falls between its weight slabs CG_PP_K - 1 and CG_PP_K.  While one wave of a SIMD is in its top-of-step work (800 - 1000 cycles
+// without a single MFMA: tools/cg_prof.py) its partner is in the MFMA half of its own step.  r04 loop form only (CG_MIDBAR 0).
+// Same MFMAs on the same operands in the same order per accumulator: bit-identical results.
+#ifndef CG_PINGPONG
+#define CG_PINGPONG 0
+#endif
+#ifndef CG_PP_K
+#define CG_PP_K 3
+#endif
+
+#if CG_PROF
+__device__ unsigned g_cg_prof[2048 * 8 * 8];       // [workgroup][wave][8]
+#define CGP_NOW() ((unsigned)__builtin_readcyclecounter())
+#endif
 
 template <int BM>
 struct CGeo {
@@ -63,9 +92,13 @@ struct CgUnit { f32x4 x0, x1, g0, g1, b0, b1; };
 // with vmcnt(0) (measured: ~1300 cycles per staging round, the round trip of the weight DMA issued just before).  The loads are
 // inline asm (invisible to the compiler's counter) and the wait carries the loaded registers as in/out operands, so that no
 // consumer can be scheduled above it.
-__device__ __forceinline__ f32x4 gload128(const float* p) {
+// (r06) scalar-base form: the tensor's base is wave-uniform (an SGPR pair), the lane's part a 32-bit BYTE offset -- no 64-bit address
+// arithmetic or address register pair per load (the HASRAW instantiations of BM = 256 spilled 172 / 224 B per lane on the 64-bit form);
+// convgn_ok bounds every staged tensor to < 4 GiB
+template <int IMM>
+__device__ __forceinline__ f32x4 gload128(const float* base, unsigned off) {
     f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(off), "s"(base), "n"(IMM));
     return v;
 }
 template <int N, bool SPADE>
@@ -98,15 +131,15 @@ __device__ __forceinline__ void cg_convert(const CgUnit& u, const float (&sc)[8]
             for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
         }
     }
-    uint32_t h[8], l[8];
+    uint32_t hp[4], lp[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split_op(y[e], 2, h[e], l[e]);
+    for (int e = 0; e < 4; ++e) split_op2(y[2 * e], y[2 * e + 1], 2, hp[e], lp[e]);
     // status word (common.h): 4 v_max3 + 1 compare per 8 values, the flag lives in an SGPR pair.  Only values that are actually STAGED count:
     // a halo / unused slot converts whatever a stand-in pixel holds and then writes zeros (tools/find_saturation.py: those lanes raised the
     // bit in 5 - 10 of 400 steps of the benchmark, the real pixels in none)
     sat |= !zero && op_sat8(y);
-    hi = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-    lo = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    hi = u32x4{hp[0], hp[1], hp[2], hp[3]};
+    lo = u32x4{lp[0], lp[1], lp[2], lp[3]};
     if (zero) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
 }
 
@@ -119,7 +152,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = CG_PINGPONG ? wave & 3 : wave >> 1, wn = CG_PINGPONG ? wave >> 2 : wave & 1;      // (ping-pong: a SIMD's two waves w, w + 4 = the two column halves of one row block)
+#if CG_PROF
+    unsigned cgp[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const unsigned cgp_t0 = CGP_NOW();
+    unsigned cgp_prev = cgp_t0, cgp_a = 0u;
+#endif
 
     const int tiles_n = d.N / BN;
     const int nb = (d.M / BM) * tiles_n;
@@ -217,15 +255,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
 
     auto load_unit = [&](int c, int p, CgUnit& u) {   // chunk c of the (virtually concatenated) GroupNorm input at pixel p
         const int ch = c * 32 + cu;
-        const float* src = ch < C1 ? x1 + (int64_t)p * C1 + ch : x2 + (int64_t)p * C2 + (ch - C1);
-        u.x0 = gload128(src);
-        u.x1 = gload128(src + 4);
+        const bool first = c * 32 < C1;                // wave-uniform: a 32-channel chunk lies in ONE of the two concatenated tensors
+        const float* base = first ? x1 : x2;
+        const int Cs = first ? C1 : C2, c0s = first ? c * 32 : c * 32 - C1;      // (scalar selects: one multiply per lane, nothing per-tensor to hoist)
+        const unsigned off = (unsigned)(p * Cs + c0s + cu) * 4u;
+        u.x0 = gload128<0>(base, off);
+        u.x1 = gload128<16>(base, off);
         if constexpr (SPADE) {
-            const int64_t o = (int64_t)p * C + ch;
-            u.g0 = gload128(gam + o);
-            u.g1 = gload128(gam + o + 4);
-            u.b0 = gload128(bet + o);
-            u.b1 = gload128(bet + o + 4);
+            const unsigned o = (unsigned)(p * C + ch) * 4u;
+            u.g0 = gload128<0>(gam, o);
+            u.g1 = gload128<16>(gam, o);
+            u.b0 = gload128<0>(bet, o);
+            u.b1 = gload128<16>(bet, o);
         }
     };
     bool sat = false;                                 // an operand value beyond the fp16 planes' range was staged (common.h status word)
@@ -266,12 +307,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     const int RC1 = d.raw_C1, RC2 = d.raw_C2;
     auto raw_load = [&](int s, CgUnit (&u)[RU]) {      // s: index within this slice's raw chunks
         const int ch = (rb + s) * 32 + cu;
+        const bool first = (rb + s) * 32 < RC1;        // wave-uniform, as in load_unit
+        const float* base = first ? rx1 : rx2;
+        const int RCs = first ? RC1 : RC2, rc0 = first ? (rb + s) * 32 : (rb + s) * 32 - RC1;
 #pragma unroll
         for (int q = 0; q < RU; ++q) {
-            const int64_t p = (int64_t)m0 + q * 128 + (t >> 2);
-            const float* src = ch < RC1 ? rx1 + p * RC1 + ch : rx2 + p * RC2 + (ch - RC1);
-            u[q].x0 = gload128(src);
-            u[q].x1 = gload128(src + 4);
+            const int p = m0 + q * 128 + (t >> 2);
+            const unsigned off = (unsigned)(p * RCs + rc0 + cu) * 4u;
+            u[q].x0 = gload128<0>(base, off);
+            u[q].x1 = gload128<16>(base, off);
         }
     };
     auto raw_write = [&](auto yc, int buf, CgUnit (&u)[RU]) {
@@ -294,13 +338,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     int b_off[3];                                     // element offsets (< 2^31: checked by the launcher)
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const int q = wave + 8 * p, plane = q / 12, rc = q - 12 * plane;
+        int q = wave + 8 * p, plane = q / 12, rc = q - 12 * plane;
+        if constexpr (CG_PINGPONG) {      // this group's column half = chunks 6 wn .. 6 wn + 5 of each plane: twelve chunks on four waves
+            q = (wave & 3) + 4 * p; plane = q / 6; rc = 6 * wn + (q - 6 * plane);
+        }
         const int n = n0 + chan_of_pos(rc * 16 + lrow);               // permuted weight rows: see tile_epilogue
         b_off[p] = (int)((int64_t)plane * d.b_lo + (int64_t)n * d.ldb + lq * 8);
     }
     bool in_loop = false;
     auto issue_w = [&](int64_t koff, int stage) {
         if ((CG_ABLATE & 16) && in_loop) return;
+        if constexpr (CG_PINGPONG) {
+            unsigned char* dstp = smem + W0 + stage * WSTAGE;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int q = (wave & 3) + 4 * p, plane = q / 6, rc = 6 * wn + (q - 6 * plane);
+                int bo = b_off[p];
+                asm volatile("" : "+v"(bo));
+                __builtin_amdgcn_global_load_lds((gptr_t)(Bb + koff + bo), (lptr_t)(dstp + plane * WPLANE + rc * 1024), 16, 0, 0);
+            }
+            return;
+        }
         unsigned char* dst = smem + W0 + stage * WSTAGE + wave * 1024;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -309,7 +367,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             __builtin_amdgcn_global_load_lds((gptr_t)(Bb + koff + bo), (lptr_t)(dst + p * 8192), 16, 0, 0);
         }
     };
-
     // ---- fragment addressing ----
     const int frow = lane & 15, kg = lane >> 4;
     // patch slot of this lane's output pixel of m-tile i (centre tap) = sb0 + soff[i], its row in a dense raw tile = rb0 + 16 i:
@@ -330,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
 
     // one k-step: A fragments from `abase` (a patch buffer or a dense tile, both planes PPLANE apart) at slots sb[i] + shift,
     // weight fragments from stage `ws`; hi*lo + lo*hi + hi*hi per tile, reads in order of first use (the ring kernel's plain loop)
-    auto mma_step = [&](unsigned abase, bool dense, int shift, int ws) {
+    auto mma_step = [&](unsigned abase, bool dense, int shift, int ws, auto&& hook, auto&& after) {
         unsigned aa[TM];
         int s0 = dense ? rb0 : sb0;
         asm volatile("" : "+v"(s0));                   // recomputed per step on purpose: hoisted, the 9 x TM addresses spill
@@ -352,36 +409,72 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
                 if constexpr (CG_ABLATE & 8) { if (i == 0) fa[p][0] = lds_read128(aa[0] + p * PPLANE); else fa[p][i] = fa[p][0]; }
                 else fa[p][i] = lds_read128(aa[i] + p * PPLANE);
             }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (j + 1 < TN) {
+        if constexpr (CG_PINGPONG && CG_PP_K == 0) {      // the other group's boundary BEFORE this step's first MFMA: the fragment reads just issued stay in
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + 2 * TM) : "memory");      // flight across it, this wave's patch / tile writes (older) have landed
+            __builtin_amdgcn_s_barrier();
+        }
+        // weight slab j: its fragment was fetched one slab ahead; `hook` runs at the head of the LAST slab (every fragment of the step is
+        // in registers: CG_MIDBAR's barrier), `after(j)` behind slab j's MFMAs (unused in the shipped forms: a hook for experiments)
+        static_for<0, TN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (CG_PINGPONG && j == CG_PP_K && CG_PP_K > 0) {      // the OTHER group's step boundary: this slab's weight fragment is the only read in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (j + 1 < TN) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) fb[(j + 1) & 1][p] = lds_read128(sbb + p * WPLANE + (j + 1) * 16 * 64);
-                if (j > 0) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                if constexpr (j > 0) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                hook();
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CG_ABLATE & 4) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (j == 0) {      // outstanding after slab i's fragments: the later slabs' + the prefetched weight fragment
-                    if (i == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM - 1) + 2) : "memory");
-                    else if (i == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM > 1 ? 2 * (TM - 2) + 2 : 0) : "memory");
-                    else if (i == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM > 2 ? 2 * (TM - 3) + 2 : 0) : "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fb[j & 1][0]), "v"(fb[j & 1][1]), "v"(fa[0][i]), "v"(fa[1][i]));
+            } else if constexpr (j == 0) {
+                // first slab: the MFMAs of pixel slabs i0 .. i0 + GI - 1 start as soon as THEIR fragments are back (outstanding after them: the
+                // later slabs' + the prefetched weight fragment).  (r06) inside a group pass-major -- hi*lo of every slab, then lo*hi, then
+                // hi*hi -- so that no MFMA follows one on its own accumulator (igemm_shared.h FRIDO_SLAB0; 0: groups of one = r04's order)
+                constexpr int GI = FRIDO_SLAB0 == 0 ? 1 : (FRIDO_SLAB0 == 2 ? TM : 2);
+                static_for<0, TM / GI>([&](auto gc) {
+                    constexpr int i0 = decltype(gc)::value * GI;
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM - GI - i0) + 2) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ii = 0; ii < GI; ++ii) acc[i0 + ii][0] = mfma_op<2>(fb[0][0], fa[1][i0 + ii], acc[i0 + ii][0]);      // weights first: C^T tiles (see tile_epilogue)
+#pragma unroll
+                    for (int ii = 0; ii < GI; ++ii) acc[i0 + ii][0] = mfma_op<2>(fb[0][1], fa[0][i0 + ii], acc[i0 + ii][0]);
+#pragma unroll
+                    for (int ii = 0; ii < GI; ++ii) acc[i0 + ii][0] = mfma_op<2>(fb[0][0], fa[0][i0 + ii], acc[i0 + ii][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else if constexpr (FRIDO_SLAB0 != 0) {      // pass-major: a dependent MFMA always has TM - 1 independent ones in front
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[1][i], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_op<2>(fb[j & 1][1], fa[0][i], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[0][i], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[1][i], acc[i][j]);
+                    acc[i][j] = mfma_op<2>(fb[j & 1][1], fa[0][i], acc[i][j]);
+                    acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[0][i], acc[i][j]);
                 }
-                if constexpr (CG_ABLATE & 4) { asm volatile("" ::"v"(fb[j & 1][0]), "v"(fb[j & 1][1]), "v"(fa[0][i]), "v"(fa[1][i])); continue; }
-                acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[1][i], acc[i][j]);      // weights first: C^T tiles (see tile_epilogue)
-                acc[i][j] = mfma_op<2>(fb[j & 1][1], fa[0][i], acc[i][j]);
-                acc[i][j] = mfma_op<2>(fb[j & 1][0], fa[0][i], acc[i][j]);
             }
+            after(jc);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
+    auto no_hook = [] {};
+    auto no_after = [](auto) {};
 
-    // ---- prologue: weights of step 0 in flight, chunk 0 staged without overlap ----
+    // ---- prologue: weights of step 0 (mid-step barrier form: and of step 1) in flight, chunk 0 staged without overlap ----
     issue_w((int64_t)cb * 32, cb & 1);
+    if constexpr (CG_MIDBAR) issue_w((int64_t)C + cb * 32, (cb + 1) & 1);      // tap 1 of the first chunk (a slice has >= 9 steps)
     {
         CgUnit pu[NR];                 // every round's loads in flight before the first conversion (the accumulators are not live yet)
         static_for<0, NR>([&](auto rc) { stage_load(rc, cb, pu[decltype(rc)::value]); });
@@ -389,6 +482,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
     }
 
     in_loop = true;
+#if CG_PROF
+    cgp_prev = CGP_NOW();
+    cgp[5] = cgp_prev - cgp_t0;
+    const unsigned cgp_loop0 = cgp_prev;
+#endif
 #ifdef CG_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // (A/B) static priority for the second-dispatched half: MI355X_MICROARCH.md "Two waves per SIMD" item 4
 #endif
@@ -424,12 +522,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
                 wait_vmcnt<0>();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's patch / tile writes have landed
+#if CG_PROF
+            cgp_a = CGP_NOW(); cgp[0] += cgp_a - cgp_prev;
+#endif
             if constexpr (!(CG_ABLATE & 128)) __builtin_amdgcn_s_barrier();
+#if CG_PROF
+            cgp_prev = CGP_NOW(); cgp[1] += cgp_prev - cgp_a;
+#endif
             // (a) weights of the next step
             if constexpr (T < 8) issue_w((int64_t)(T + 1) * C + c * 32, (c + T + 1) & 1);
             else if constexpr (MODE == 0) issue_w((int64_t)(c + 1) * 32, (c + 1) & 1);                 // tap 0 of chunk c + 1: stage (9 (c + 1)) & 1
             else if constexpr (MODE == 2) issue_w((int64_t)9 * C + rb * 32, (c + 1) & 1);               // this slice's first raw tile
-            using Y3 = std::integral_constant<int, 3>;       // (dependency only: the unit's loads completed at this step's top wait)
+            // (dependency only: the unit's loads completed at this step's top wait -- except the late waves' last round and the raw tile, which
+            //  the count behind the three DMA pieces just issued really waits for)
+            using Y3 = std::integral_constant<int, 3>;
+            using YL = Y3;
             if constexpr (MODE == 0) {
                 constexpr int EC = (T % 2 == 0 && T >= 2 && T / 2 - 1 < NR) ? T / 2 - 1 : -1;          // round the early waves convert
                 constexpr int EL = (T % 2 == 0 && T / 2 < NR) ? T / 2 : -1;                            // ... and load
@@ -439,7 +546,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
                     if constexpr (EC >= 0) stage_write(std::integral_constant<int, EC < 0 ? 0 : EC>{}, Y3{}, c + 1, su);
                     if constexpr (EL >= 0) stage_load(std::integral_constant<int, EL < 0 ? 0 : EL>{}, c + 1, su);
                 } else {
-                    if constexpr (LC >= 0) stage_write(std::integral_constant<int, LC < 0 ? 0 : LC>{}, Y3{}, c + 1, su);
+                    if constexpr (LC >= 0) stage_write(std::integral_constant<int, LC < 0 ? 0 : LC>{}, YL{}, c + 1, su);
                     if constexpr (LL >= 0) stage_load(std::integral_constant<int, LL < 0 ? 0 : LL>{}, c + 1, su);
                 }
             }
@@ -449,12 +556,107 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
             if (early) {
                 if constexpr (RAWW) raw_write(Y3{}, (c + 1) & 1, ru);
             }
-            mma_step(lds0 + (unsigned)((c & 1) * PBUF), false, (T / 3 - 1) * PW + (T % 3 - 1), (c + T) & 1);
+#if CG_PROF
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cgp_a = CGP_NOW(); cgp[2] += cgp_a - cgp_prev;
+#endif
+            mma_step(lds0 + (unsigned)((c & 1) * PBUF), false, (T / 3 - 1) * PW + (T % 3 - 1), (c + T) & 1, no_hook, no_after);
+#if CG_PROF
+            cgp_prev = CGP_NOW(); cgp[3] += cgp_prev - cgp_a;
+#endif
             if (!early) {
-                if constexpr (RAWW) raw_write(Y3{}, (c + 1) & 1, ru);
+                if constexpr (RAWW) raw_write(YL{}, (c + 1) & 1, ru);
             }
         });
     };
+    // ---- (r06) MID-STEP BARRIER form.  r04 met at the TOP of every step (54 - 66 times per launch): after the release a wave first issues
+    // its weight DMA, converts a staging round, computes fragment addresses and waits out an LDS round trip -- with both waves of every SIMD
+    // at the same point, the matrix pipe idles for those few hundred cycles of every ~2700-cycle step.  Here step g's barrier sits at the
+    // head of its LAST weight slab: all of the wave's fragments of the step are in registers (its reads of weight stage g & 1 are over),
+    // TM MFMA triples are ready to issue right after the release, and the top-of-step work of step g + 1 is no longer aligned across waves
+    // (the older wave of a SIMD runs ahead into it while the younger one still issues MFMAs).  Ring protocol (2 weight stages, as before):
+    //   hook of step g:  lgkmcnt(0) [mma_step]; my share of W(g + 1) has landed (vmcnt: only loads issued at THIS step's top are younger);
+    //                    s_barrier  -> W(g + 1) and every patch / raw-tile write before it are published, stage g & 1 is free;
+    //                    issue W(g + 2) into stage g & 1 (one full step ahead, like r04's tap-ahead DMA).
+    // Patch buffers: a round of chunk c + 1 is written at a step's top into the buffer chunk c - 1 read; all of those reads (issued at a
+    // step's top) lie before that chunk's tap-8 hook.  Raw tile s + 1 is written at the top of raw step s into the buffer step s - 1 read.
+    // A staged unit loaded at the top of step g is converted at the top of step g + 2 (g + 1 for the late waves' last round): the hook of
+    // step g + 1 has drained it (a wave never loads at two consecutive steps), so the conversion's wait (vmcnt(3): the DMA just issued) is
+    // a dependency only, as in r04.
+    if constexpr (CG_MIDBAR) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // chunk 0's patch written, both weight stages landed
+        __builtin_amdgcn_s_barrier();
+        using Y3 = std::integral_constant<int, 3>;
+        auto chunk_mb = [&](auto modec, int c) {
+            constexpr int MODE = decltype(modec)::value;
+            static_for<0, 9>([&](auto tc) {
+                constexpr int T = decltype(tc)::value;
+                // ---- top of the step: staging of chunk c + 1 (MODE 0) / the raw tiles (MODE 2); no barrier ----
+                constexpr int EL = (MODE == 0 && T % 2 == 0 && T / 2 < NR) ? T / 2 : -1;                       // round the early waves load
+                constexpr int LL = (MODE == 0 && T % 2 == 1 && (T - 1) / 2 < NR) ? (T - 1) / 2 : -1;           // ... the late waves
+                if constexpr (MODE == 0) {
+                    constexpr int EC = (T % 2 == 0 && T >= 2 && T / 2 - 1 < NR) ? T / 2 - 1 : -1;              // round the early waves convert
+                    constexpr int LC = (T % 2 == 1 && T >= 3 && (T - 3) / 2 < NR) ? (T - 3) / 2 : ((T == 8 && NR == 4) ? 3 : -1);
+                    if (early) {
+                        if constexpr (EC >= 0) stage_write(std::integral_constant<int, EC < 0 ? 0 : EC>{}, Y3{}, c + 1, su);
+                        if constexpr (EL >= 0) stage_load(std::integral_constant<int, EL < 0 ? 0 : EL>{}, c + 1, su);
+                    } else {
+                        if constexpr (LC >= 0) stage_write(std::integral_constant<int, LC < 0 ? 0 : LC>{}, Y3{}, c + 1, su);
+                        if constexpr (LL >= 0) stage_load(std::integral_constant<int, LL < 0 ? 0 : LL>{}, c + 1, su);
+                    }
+                }
+                if constexpr (MODE == 2 && T == 0) raw_load(0, ru);
+                if constexpr (MODE == 2 && T == 1) raw_write(Y3{}, (c + 1) & 1, ru);            // tile 0 -> the buffer chunk c - 1 read
+                if constexpr (MODE == 2 && T == 6) { if (nraw > 1) raw_load(1, ru); }
+                mma_step(lds0 + (unsigned)((c & 1) * PBUF), false, (T / 3 - 1) * PW + (T % 3 - 1), (c + T) & 1, [&] {
+                    // my share of the NEXT step's weights has landed: only the loads issued at this step's top may stay in flight
+                    if constexpr (MODE == 0) {
+                        constexpr int E = EL >= 0 ? NL : 0, L = LL >= 0 ? NL : 0;
+                        if constexpr (E == L) wait_vmcnt<E>();
+                        else if (early) wait_vmcnt<E>();
+                        else wait_vmcnt<L>();
+                    } else if constexpr (MODE == 2 && T == 0) {
+                        wait_vmcnt<2 * RU>();
+                    } else if constexpr (MODE == 2 && T == 6) {
+                        if (nraw > 1) wait_vmcnt<2 * RU>(); else wait_vmcnt<0>();
+                    } else {
+                        wait_vmcnt<0>();
+                    }
+                    if constexpr (!(CG_ABLATE & 128)) __builtin_amdgcn_s_barrier();
+                    // refill the stage this step has finished reading with the weights of step + 2
+                    if constexpr (T + 2 <= 8) issue_w((int64_t)(T + 2) * C + c * 32, (c + T) & 1);
+                    else if constexpr (MODE == 0) issue_w((int64_t)(T + 2 - 9) * C + (c + 1) * 32, (c + T) & 1);
+                    else if constexpr (MODE == 2) { if (T + 2 - 9 < nraw) issue_w((int64_t)9 * C + (rb + T + 2 - 9) * 32, (c + T) & 1); }
+                }, no_after);
+            });
+        };
+        for (int c = cb; c + 1 < nc; ++c) chunk_mb(std::integral_constant<int, 0>{}, c);
+        if (HASRAW && nraw > 0) {
+            chunk_mb(std::integral_constant<int, 2>{}, nc - 1);
+            // raw tile s: weights in stage (nc + s) & 1, tile in patch buffer (nc + s) & 1
+            for (int s = 0; s < nraw; ++s) {
+                const bool nxt = s + 1 < nraw, nxt2 = s + 2 < nraw;
+                if (nxt) {
+                    raw_write(Y3{}, (nc + s + 1) & 1, ru);      // tile s + 1 -> the buffer step s - 1 read (loaded at the top of step s - 1 / tap 6)
+                    if (nxt2) raw_load(s + 2, ru);
+                }
+                mma_step(lds0 + (unsigned)(((nc + s) & 1) * PBUF), true, 0, (nc + s) & 1, [&] {
+                    if (nxt && nxt2) wait_vmcnt<2 * RU>(); else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    if (nxt2) issue_w((int64_t)9 * C + (rb + s + 2) * 32, (nc + s) & 1);
+                }, no_after);
+            }
+        } else {
+            chunk_mb(std::integral_constant<int, 1>{}, nc - 1);
+        }
+    } else {
+    if constexpr (CG_PINGPONG) {
+        static_assert(!CG_MIDBAR && CG_PP_K >= 0 && CG_PP_K < TN, "ping-pong: r04 loop form");
+        if (!early) {      // group Y starts half a step late: it sits out barrier A_0 (group X's first top)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
     for (int c = cb; c + 1 < nc; ++c) chunk(std::integral_constant<int, 0>{}, c);
     if (HASRAW && nraw > 0) {
         chunk(std::integral_constant<int, 2>{}, nc - 1);
@@ -470,12 +672,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
                 raw_write(std::integral_constant<int, 3>{}, (nc + s + 1) & 1, ru);      // tile s + 1 -> the buffer step s - 1 read
                 if (s + 2 < nraw) raw_load(s + 2, ru);
             }
-            mma_step(lds0 + (unsigned)(((nc + s) & 1) * PBUF), true, 0, (nc + s) & 1);
+            mma_step(lds0 + (unsigned)(((nc + s) & 1) * PBUF), true, 0, (nc + s) & 1, no_hook, no_after);
         }
     } else {
         chunk(std::integral_constant<int, 1>{}, nc - 1);
     }
+    if constexpr (CG_PINGPONG) {
+        if (early) __builtin_amdgcn_s_barrier();      // barrier A_n: the mid-step barrier of group Y's last step
+    }
+    }      // (!CG_MIDBAR)
     wait_vmcnt<0>();
+#if CG_PROF
+    const unsigned cgp_loop1 = CGP_NOW();
+    cgp[4] = cgp_loop1 - cgp_loop0;
+#endif
     status_raise(sat);
     if constexpr (CG_ABLATE & 32) {       // (timing only) no epilogue: keep the accumulators live, store nothing
         float sink = 0.f;
@@ -483,8 +693,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         if (sink == 1.2345e-30f) d.out_f32[0] = sink;
         return;
     }
-    tile_epilogue<BM, BN, 2, WM, false>(d, acc, smem, m0, n0, wave, lane, 0, 0, kz);
+    tile_epilogue<BM, BN, 2, WM, false>(d, acc, smem, m0, n0, CG_PINGPONG ? wm * 2 + wn : wave, lane, 0, 0, kz);      // (the epilogue's wave id = 2 wm + wn)
+#if CG_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left the wave (not: reached memory)
+    cgp[6] = CGP_NOW() - cgp_loop1;
+    if (lane == 0 && bid < 2048 && kz == 0) {
+        unsigned* o = g_cg_prof + (bid * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = cgp[i];
+    }
+#endif
 }
+
+#if CG_PROF
+extern "C" int frido_cg_prof_read(unsigned* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cg_prof), (size_t)n * sizeof(unsigned), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // eligibility of the fused GroupNorm + conv kernel (tile ids 20 = BM 256, 21 = BM 128)
 bool convgn_ok(const FridoGemm& d, int bm) {
@@ -506,6 +731,12 @@ bool convgn_ok(const FridoGemm& d, int bm) {
     }
     if (d.geglu || d.out_u8 || (d.flags & 4)) return false;
     if (2 * d.b_lo + (int64_t)d.N * d.ldb >= (1ll << 31)) return false;      // 32-bit weight offsets in the kernel
+    {   // (r06) the staging loads address every staged tensor as base (SGPR pair) + 32-bit BYTE offset: rows x widest row < 4 GiB
+        int cw = C;                                                            // gamma / beta rows are C wide, x1 / x2 rows narrower
+        if (d.raw_C1 > cw) cw = d.raw_C1;
+        if (d.raw_C2 > cw) cw = d.raw_C2;
+        if ((int64_t)d.M * cw >= (1ll << 30)) return false;
+    }
     return true;
 }
 

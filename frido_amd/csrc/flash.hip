@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void flash_attn_kernel(co
         {
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) split_op(pv[i], NS, h[i], l[i]);
+            for (int i = 0; i < 8; i += 2) { split_op2(pv[i], pv[i + 1], NS, h[i], l[i]); h[i + 1] = 0u; l[i + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
             u32x4 ph = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
             pf[0] = __builtin_bit_cast(bf16x8, ph);
             if constexpr (NS == 2) {
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512, 1) void flash_ds_kernel(const FridoAttnSmall d
         {
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) split_op(pv[i], NS, h[i], l[i]);
+            for (int i = 0; i < 8; i += 2) { split_op2(pv[i], pv[i + 1], NS, h[i], l[i]); h[i + 1] = 0u; l[i + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
             u32x4 ph = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
             u32x4 pl = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
             pf[0] = __builtin_bit_cast(bf16x8, ph);

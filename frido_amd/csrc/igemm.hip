@@ -638,13 +638,24 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
     } else {
     // ---- plain loop (bf16 BK = 32 tiles; bf16x3 tiles with six n-tiles per wave, whose second fragment sets would spill: those run
     //      as TWO 4-wave workgroups per CU on a 2-slot ring, the other workgroup's MFMAs covering this one's read phase) ----
-    // ---- prologue: fill D-1 stages ----
+    // (r06) MID-STEP BARRIER form of the two-slot two-plane tiles (128 x 192, 64 x 192, 256 x 192; convgn.hip has the long version): k-tile kt's
+    // barrier sits at the head of its LAST weight slab -- every fragment of the tile is in registers, TM MFMA triples are ready right after
+    // the release -- instead of at its top, where the release is followed by the DMA issue and an LDS round trip with the matrix pipe idle.
+    // Hook of k-tile kt: my share of tile kt + 1 has landed (vmcnt(0): it is all that is in flight), barrier (tile kt + 1 published, slot
+    // kt & 1 free), issue tile kt + 2 into slot kt & 1.  Same MFMAs, same operands, same order: bit-identical results.
+    constexpr bool MIDBAR = FRIDO_MIDBAR != 0 && NS == 2 && D == 2 && KG == 1 && TN > 1 && BK == 32;
+    // ---- prologue: fill D-1 stages (mid-step form: both slots) ----
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s)
+    for (int s = 0; s < D - 1 + (MIDBAR ? 1 : 0); ++s)
         if (s < nk) issue(s);
+    if constexpr (MIDBAR) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
 
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
+        if constexpr (!MIDBAR) {
         // tile kt must have landed: at most the loads of the (D-2) younger tiles may stay in flight
         if (kt + D - 2 < nk) wait_vmcnt<(D - 2) * G::LPT>();
         else wait_tail<D - 3, G::LPT>(nk - 1 - kt);
@@ -653,6 +664,7 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
             int nb_ = buf + D - 1;
             nb_ = nb_ >= D ? nb_ - D : nb_;
             issue(nb_);
+        }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -678,8 +690,31 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
                     if (j > 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS) : "memory");
                 } else {
                     if (j > 0 || TN == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (MIDBAR) {
+                        wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        if (kt + 2 < nk) issue(buf);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FRIDO_SLAB0 != 0 && NS == 2 && TN > 1 && (TM & 1) == 0) {
+                    if (j == 0) {      // (r06) pixel slabs in groups of GI, pass-major inside a group (igemm_shared.h FRIDO_SLAB0)
+                        constexpr int GI = FRIDO_SLAB0 == 2 ? TM : 2;
+                        static_for<0, TM / GI>([&](auto gc) {
+                            constexpr int i0 = decltype(gc)::value * GI;
+                            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NS * (TM - GI - i0) + NS) : "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int ii = 0; ii < GI; ++ii) acc[i0 + ii][0] = mfma_op<NS>(fb[0][0], fa[1][i0 + ii], acc[i0 + ii][0]);
+#pragma unroll
+                            for (int ii = 0; ii < GI; ++ii) acc[i0 + ii][0] = mfma_op<NS>(fb[0][1], fa[0][i0 + ii], acc[i0 + ii][0]);
+#pragma unroll
+                            for (int ii = 0; ii < GI; ++ii) acc[i0 + ii][0] = mfma_op<NS>(fb[0][0], fa[0][i0 + ii], acc[i0 + ii][0]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     if (j == 0 && TN > 1) {     // outstanding after slab i's fragments: the later slabs' + the prefetched weight fragment
@@ -1358,7 +1393,7 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const FridoGemm d) 
         if (d.out_op) {
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split_op(v[e], d.nsplit, h[e], l[e]);
+            for (int e = 0; e < 8; e += 2) { split_op2(v[e], v[e + 1], d.nsplit, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
             if (d.nsplit == 2) sat |= op_sat8(v);
             frido_bf16* op = d.out_op + (int64_t)m * d.ldoo + n;
             *reinterpret_cast<uint4*>(op) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));

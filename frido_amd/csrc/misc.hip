@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const FridoPack d) {
             const float v[8] = {a.x * d.scale, a.y * d.scale, a.z * d.scale, a.w * d.scale, b.x * d.scale, b.y * d.scale, b.z * d.scale, b.w * d.scale};
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split_op(v[e], 2, h[e], l[e]);
+            for (int e = 0; e < 8; e += 2) { split_op2(v[e], v[e + 1], 2, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
             sat |= op_sat8(v);
             frido_bf16* o = d.out_op + pix * d.Cpad + c;
             *reinterpret_cast<uint4*>(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));

@@ -290,14 +290,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const FridoGnApply d) {
             }
             uint32_t h[8], l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split_op(y[e], 2, h[e], l[e]);
+            for (int e = 0; e < 8; e += 2) { split_op2(y[e], y[e + 1], 2, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
             sat |= op_sat8(y);
             *reinterpret_cast<uint4*>(d.out_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             *reinterpret_cast<uint4*>(d.out_op + d.out_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             if (d.raw_op) {                 // concatenated raw operand for the 1x1 skip conv
                 sat |= op_sat8(xin);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split_op(xin[e], 2, h[e], l[e]);
+                for (int e = 0; e < 8; e += 2) { split_op2(xin[e], xin[e + 1], 2, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
                 *reinterpret_cast<uint4*>(d.raw_op + v.o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 *reinterpret_cast<uint4*>(d.raw_op + d.raw_lo + v.o) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
@@ -554,7 +554,7 @@ template <int VW>
 __device__ __forceinline__ void store_planes(frido_bf16* op, int64_t lo_off, int nsplit, const float (&y)[VW]) {
     uint32_t h[VW], l[VW];
 #pragma unroll
-    for (int e = 0; e < VW; ++e) split_op(y[e], nsplit, h[e], l[e]);
+    for (int e = 0; e < VW; e += 2) { split_op2(y[e], y[e + 1], nsplit, h[e], l[e]); h[e + 1] = 0u; l[e + 1] = 0u; }      // (r06) packed pair: h[even] | (0 << 16)
     if constexpr (VW == 8) {
         *reinterpret_cast<u32x4*>(op) = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         if (nsplit == 2)
@@ -634,6 +634,15 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
             }
         }
     }
+    // (r06) the affine parameters too: after the second barrier their loads sat on the launch's latency chain (a workgroup fence keeps the
+    // compiler from hoisting them) -- one L2 round trip in every one of the 34 launches of a forward
+    // (not in the 1024-thread x 8-channel form: 128 registers per lane, the 16 more would spill)
+    constexpr bool EARLY_AFFINE = !(NT == 1024 && VW == 8);
+    float wgt[VW], bia[VW];
+    if constexpr (EARLY_AFFINE) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { wgt[e] = live ? d.weight[c + e] : 0.f; bia[e] = live ? d.bias[c + e] : 0.f; }
+    }
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < VW; ++e)
@@ -663,9 +672,10 @@ __global__ __launch_bounds__(NT) void gn_fused_f32_kernel(const FridoGnApply d, 
     float sc[VW], sh[VW];
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
-        const float r = s_rstd[gi[e]] * d.weight[c + e];
+        if constexpr (!EARLY_AFFINE) { wgt[e] = d.weight[c + e]; bia[e] = d.bias[c + e]; }
+        const float r = s_rstd[gi[e]] * wgt[e];
         sc[e] = r;
-        sh[e] = d.bias[c + e] - s_mean[gi[e]] * r;
+        sh[e] = bia[e] - s_mean[gi[e]] * r;
     }
     bool sat = false;
 #pragma unroll

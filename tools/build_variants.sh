@@ -8,14 +8,16 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   (
     src=frido_amd/csrc
-    if [ "$name" = head ]; then
+    rest="frido_amd/csrc/norm.o frido_amd/csrc/misc.o frido_amd/csrc/attn.o frido_amd/csrc/flash.o frido_amd/csrc/runtime.o"
+    if [ "$name" = head ]; then      # EVERY source as committed at HEAD
       src=/tmp/variants_head; rm -rf $src; mkdir -p $src
-      for f in igemm.hip convgn.hip igemm_shared.h common.h; do git show HEAD:frido_amd/csrc/$f > $src/$f; done
+      for f in igemm.hip convgn.hip igemm_shared.h common.h norm.hip misc.hip attn.hip flash.hip runtime.hip; do git show HEAD:frido_amd/csrc/$f > $src/$f; done
+      rest=""
+      for f in norm misc attn flash runtime; do /opt/rocm/bin/hipcc $FL -I$src -c $src/$f.hip -o tools/ablate/${f}_head.o; rest="$rest tools/ablate/${f}_head.o"; done
     fi
     /opt/rocm/bin/hipcc $FL -I$src $flags -c $src/igemm.hip -o tools/ablate/igemm_$name.o &&
     /opt/rocm/bin/hipcc $FL -I$src $flags -c $src/convgn.hip -o tools/ablate/convgn_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/ablate/igemm_$name.o tools/ablate/convgn_$name.o \
-        frido_amd/csrc/{norm,misc,attn,flash,runtime}.o -o tools/ablate/libfrido_$name.so
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/ablate/igemm_$name.o tools/ablate/convgn_$name.o $rest -o tools/ablate/libfrido_$name.so
   ) &
 done
 wait

@@ -92,4 +92,47 @@ call4() {
   cat $OUT/r06_slab0_end_to_end_ab.txt
 }
 
-"${1:?call1 | call2 | call3 | call4}"
+call5() {
+  # Round-6 GPU call 5: the fused GroupNorm + conv kernel with its step barrier INSIDE the k-step (CG_MIDBAR, convgn.hip;
+  # tools/build_variants.sh mb1 "" mb0 -DCG_MIDBAR=0 beforehand): gate on the new default build, per-launch times, interleaved end-to-end A/B.
+  R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; OUT=$R/gpurun_out; mkdir -p $OUT
+  ( time python -m pytest tests -m "gpu and gate" -q -x --durations=5 > $OUT/r06c5_gate.log 2>&1 ) 2> $OUT/r06c5_gate.time; tail -5 $OUT/r06c5_gate.log; cat $OUT/r06c5_gate.time
+  python -m pytest tests/test_kernels_gpu.py -q -x -k "gn_conv or convgn or fused" > $OUT/r06c5_convgn_tests.log 2>&1; tail -3 $OUT/r06c5_convgn_tests.log
+  ( for i in 1 2; do for v in mb0 mb1; do
+      export FRIDO_LIB=$R/tools/ablate/libfrido_$v.so
+      echo "== $v"
+      python tools/gnconv_bench.py 16 64 64 192 0 192 0 0 20 2>&1 | grep -E "fused.*total|^=="
+      python tools/gnconv_bench.py 16 64 64 384 0 192 1 384 20 2>&1 | grep -E "fused.*total|^=="
+      python tools/gnconv_bench.py 16 32 32 384 0 384 0 0 21 2>&1 | grep -E "fused.*total|^=="
+    done; done ) > $OUT/r06_midbar_per_launch.txt 2>&1; cat $OUT/r06_midbar_per_launch.txt
+  unset FRIDO_LIB
+  ROUNDS=3 bash tools/ab.sh lib tools/ablate/libfrido_mb0.so tools/ablate/libfrido_mb1.so > $OUT/r06_midbar_end_to_end_ab.txt 2>&1
+  cat $OUT/r06_midbar_end_to_end_ab.txt
+}
+
+call6() {
+  # Round-6 GPU call 6: per-wave cycle accounting of the fused GroupNorm + conv kernel (tools/cg_prof.py on the -DCG_PROF=1 build)
+  R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; OUT=$R/gpurun_out; mkdir -p $OUT
+  export FRIDO_LIB=$R/tools/ablate/libfrido_prof.so
+  ( python tools/cg_prof.py 16 64 64 192 192 0 0
+    python tools/cg_prof.py 16 64 64 192 192 1 0
+    python tools/cg_prof.py 16 64 64 384 192 0 0
+    python tools/cg_prof.py 16 32 32 384 384 0 0 21
+    python tools/cg_prof.py 16 64 64 192 192 1 384 ) 2>&1 | grep -v amdgpu.ids > $OUT/r06_cg_prof.txt
+  cat $OUT/r06_cg_prof.txt
+}
+
+call7() {
+  # Round-6 GPU call 7: the SPREAD form of the fused kernel (weight DMA pieces and staging loads inside the k-step, CG_SPREAD;
+  # tools/build_variants.sh sp1 "-DCG_SPREAD=1 -DCG_MIDBAR=0" profsp "-DCG_PROF=1 -DCG_SPREAD=1 -DCG_MIDBAR=0" prof "-DCG_PROF=1 -DCG_MIDBAR=0" mb0 "-DCG_MIDBAR=0")
+  R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; OUT=$R/gpurun_out; mkdir -p $OUT
+  FRIDO_LIB=$R/tools/ablate/libfrido_sp1.so python -m pytest tests/test_kernels_gpu.py -q -x -k "gn_conv" > $OUT/r06c7_convgn_tests.log 2>&1; tail -3 $OUT/r06c7_convgn_tests.log
+  ( for v in prof profsp; do echo "#### $v"; export FRIDO_LIB=$R/tools/ablate/libfrido_$v.so
+      python tools/cg_prof.py 16 64 64 192 192 0 0; python tools/cg_prof.py 16 64 64 192 192 1 0; python tools/cg_prof.py 16 32 32 384 384 0 0 21; done ) 2>&1 | grep -v amdgpu.ids > $OUT/r06_cg_prof_spread.txt
+  cat $OUT/r06_cg_prof_spread.txt
+  unset FRIDO_LIB
+  ROUNDS=3 bash tools/ab.sh lib tools/ablate/libfrido_mb0.so tools/ablate/libfrido_sp1.so > $OUT/r06_spread_end_to_end_ab.txt 2>&1
+  cat $OUT/r06_spread_end_to_end_ab.txt
+}
+
+"${1:?call1 | call2 | call3 | call4 | call5 | call6 | call7}"
