@@ -160,7 +160,9 @@ __device__ __forceinline__ float silu_f(float v) {
 // VALU cycles, and the GEGLU epilogue evaluates it 2e8 times per denoiser forward (it was VALU-, not store-bound).
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    // (r06) v_rcp_f32: HIP's __frcp_rn is a correctly rounded 1 / x -- the full v_div_scale / v_div_fmas / v_div_fixup sequence, 11 instructions
+    // where the approximation's own error (1.5e-7) is 2.5 ulp
+    const float t = FRIDO_SILU_DIV ? __frcp_rn(fmaf(0.3275911f, ax, 1.0f)) : __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -169,7 +171,10 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(r, x);
 }
 // OpenAI CLIP's QuickGELU (clip/model.py): x * sigmoid(1.702 x)
-__device__ __forceinline__ float quickgelu_f(float v) { return v / (1.0f + __expf(-1.702f * v)); }
+__device__ __forceinline__ float quickgelu_f(float v) {
+    if constexpr (FRIDO_SILU_DIV) return v / (1.0f + __expf(-1.702f * v));
+    else return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+}
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
