@@ -47,12 +47,23 @@ int frido_convgn_init();
 // applies to from bits 16..23 in units of 64 workgroups (0 = 768 workgroups), which workgroups wait from bits 24..25.
 // Python: FRIDO_STAGGER_US (a float) / FRIDO_STAGGER_MIN_WG / FRIDO_STAGGER_MODE (engine.py).
 // (FRIDO_STAGGER_RT itself: igemm_shared.h, next to the one-workgroup-per-CU form of the experiment)
+// (r06) -DIG_PROF=1 (tools/igemm_prof.py; never in the shipped build): every wave of the two-plane virtual-step loop sums the shader cycles
+// (s_memtime) it spends, per k-tile,  [0] waiting for the next stage's DMA in front of the barrier, [1] inside the barrier, [2] in the rest of
+// its three virtual steps (MFMAs, fragment reads and their lgkmcnt waits, DMA issue);  [3] = the whole loop, [4] = kernel start -> loop,
+// [5] = epilogue, [6] = k-tiles.  Stamps sit where lgkmcnt is 0 anyway.  convgn.hip has the same for the fused kernel (CG_PROF).
+#ifndef IG_PROF
+#define IG_PROF 0
+#endif
 #ifndef FRIDO_X3_PIPE_ALL
 #define FRIDO_X3_PIPE_ALL 0      // 1: also run the six-n-tile bf16x3 tiles (128 x 192, 64 x 192) on the virtual-k-step loop
 #endif
 
 namespace {
 
+#if IG_PROF
+__device__ unsigned g_ig_prof[4096 * 8 * 8];       // [workgroup][wave][8]
+#define IGP_NOW() ((unsigned)__builtin_readcyclecounter())
+#endif
 __device__ uint4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 
 // (LDS / waitcnt helpers, xcd_item, static_for, chan_of_pos, tile_epilogue: igemm_shared.h)
@@ -111,6 +122,11 @@ __device__ __forceinline__ void wait_tail(int rem) {
 template <int BM, int BN, int NS, bool CONV, int BK, bool W8 = false, int KG = 1>
 __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS, BK, W8, KG>::NW == 8 || KG == 2) ? 1 : 2)) void igemm_kernel(const FridoGemm d) {
     using G = Geo<BM, BN, NS, BK, W8, KG>;
+#if IG_PROF
+    unsigned igp[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const unsigned igp_t0 = IGP_NOW();
+    unsigned igp_prev = igp_t0, igp_a = 0u, igp_loop0 = 0u;
+#endif
     constexpr int JBR = G::JBR;
     constexpr int ROWB = G::ROWB, CHR = G::CHR, KS = BK / 32;
     constexpr int WM = G::WMW, WN = 2, NW = G::NW;
@@ -567,9 +583,18 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
                 if constexpr (PRE) {
                     // stage kt + 1 must have landed; past this barrier every wave holds stage kt in registers: its slot is free
                     if constexpr (!(FRIDO_ABLATE & 4)) {
+#if IG_PROF
+                        igp_a = IGP_NOW(); igp[2] += igp_a - igp_prev;
+#endif
                         if (kt + D - 1 < nk) wait_stages(std::integral_constant<int, D - 2>{});
                         else wait_younger(nk - kt - 2);
+#if IG_PROF
+                        igp_prev = IGP_NOW(); igp[0] += igp_prev - igp_a; igp_a = igp_prev;
+#endif
                         __builtin_amdgcn_s_barrier();
+#if IG_PROF
+                        igp_prev = IGP_NOW(); igp[1] += igp_prev - igp_a; igp[6] += 1;
+#endif
                     }
                     nbuf = buf + 1 == D ? 0 : buf + 1;
                     ra = afr + nbuf * STAGE;
@@ -625,6 +650,9 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         int kt = 0;
+#if IG_PROF
+        igp_prev = IGP_NOW(); igp[4] = igp_prev - igp_t0; igp_loop0 = igp_prev;
+#endif
         for (; kt + 2 < nk; kt += 2) {
             vstep(I0{}, I0{}, T_{}, kt); vstep(I1{}, I0{}, T_{}, kt); vstep(I2{}, I0{}, T_{}, kt);
             vstep(I0{}, I1{}, T_{}, kt + 1); vstep(I1{}, I1{}, T_{}, kt + 1); vstep(I2{}, I1{}, T_{}, kt + 1);
@@ -635,6 +663,9 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
         } else if (kt + 1 == nk) {
             vstep(I0{}, I0{}, T_{}, kt); vstep(I1{}, I0{}, T_{}, kt); vstep(I2{}, I0{}, F_{}, kt);
         }
+#if IG_PROF
+        { const unsigned t1 = IGP_NOW(); igp[2] += t1 - igp_prev; igp[3] = t1 - igp_loop0; igp_prev = t1; }
+#endif
     } else {
     // ---- plain loop (bf16 BK = 32 tiles; bf16x3 tiles with six n-tiles per wave, whose second fragment sets would spill: those run
     //      as TWO 4-wave workgroups per CU on a 2-slot ring, the other workgroup's MFMAs covering this one's read phase) ----
@@ -816,7 +847,25 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
         reduced = true;
     }
     tile_epilogue<BM, BN, NS, WM, G::RSTAGE>(d, acc, smem, m0, n0, wave, lane, zo, zi, kz, reduced);
+#if IG_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left the wave (not: reached memory)
+    igp[5] = IGP_NOW() - igp_prev;
+    {
+        const int wg = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        if (lane == 0 && wg < 4096 && wave < 8) {
+            unsigned* o = g_ig_prof + (wg * 8 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = igp[i];
+        }
+    }
+#endif
 }
+
+#if IG_PROF
+extern "C" int frido_ig_prof_read(unsigned* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ig_prof), (size_t)n * sizeof(unsigned), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // =====================================================================================================================
 // Patch-staged 3x3 convolution (stride 1, pad 1, no resampling), bf16 mode, 256 x 192 tile, 8 waves.
