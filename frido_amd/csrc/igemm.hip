@@ -650,6 +650,11 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         int kt = 0;
+#ifdef IG_PRIO
+        // (A/B, r06) static priority for the second-dispatched half of an 8-wave workgroup: tools/igemm_prof.py shows it losing the MFMA
+        // arbitration on every k-tile (2120 against 1620 cycles) while the older half waits for it at the barrier
+        if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #if IG_PROF
         igp_prev = IGP_NOW(); igp[4] = igp_prev - igp_t0; igp_loop0 = igp_prev;
 #endif
