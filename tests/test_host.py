@@ -50,6 +50,24 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
         assert L.frido_sizeof_desc(_lib.OP_KINDS[kname]) == C.sizeof(_lib.STRUCTS[sname]), sname
 
 
+def test_shipped_libraries_are_not_profiling_or_experiment_builds():
+    """r06: -DCG_PROF / -DIG_PROF builds (tools/cg_prof.py, tools/igemm_prof.py) export a reader for their per-wave cycle sums and carry an
+    s_memtime + lgkmcnt(0) in every k-step; the loop-form experiments (CG_MIDBAR, CG_PINGPONG, FRIDO_MIDBAR) are off in what ships.  Both
+    libraries in the tree must be the plain build: no profiling entry point, and the macros' defaults in the sources say 0."""
+    import os
+    import re
+    for key in ("f16", "bf16"):
+        L = C.CDLL(_lib.LIB_PATHS[key])
+        for name in ("frido_cg_prof_read", "frido_ig_prof_read"):
+            assert not hasattr(L, name), f"{_lib.LIB_PATHS[key]} is a profiling build ({name})"
+    src = os.path.join(os.path.dirname(_lib.__file__), "csrc")
+    text = open(os.path.join(src, "convgn.hip")).read() + open(os.path.join(src, "igemm.hip")).read() + open(os.path.join(src, "igemm_shared.h")).read()
+    for macro in ("CG_PROF", "IG_PROF", "CG_MIDBAR", "CG_PINGPONG", "FRIDO_MIDBAR", "CG_ABLATE", "FRIDO_ABLATE"):
+        m = re.search(r"#ifndef %s\n#define %s (\d+)" % (macro, macro), text)
+        assert m and m.group(1) == "0", macro
+    assert re.search(r"#ifndef FRIDO_SILU_DIV\n#define FRIDO_SILU_DIV 0", open(os.path.join(src, "common.h")).read())
+
+
 def test_bad_descriptors_are_rejected_without_touching_a_device():
     L = _lib.lib()
     kind, st = _lib.make_op("FRIDO_OP_GEMM", M=16, N=16, K=20, batch=1, nsplit=1)     # K not a multiple of 32

@@ -939,6 +939,34 @@ def test_executor_side_stream_branches_join_correctly(monkeypatch):
     assert torch.equal(o0.view(), o1.view()) and torch.equal(p0.view(), p1.view())
 
 
+@pytest.mark.gate
+def test_device_plane_split_is_the_host_packers_bit_for_bit():
+    """r06: every operand producer splits PAIRS of values with split_op2 (csrc/common.h: v_cvt_pk_f16_f32 on both planes, v_pk_add_f32 for the
+    residual) instead of one value at a time.  Same roundings, so the planes must be the host packer's (torch's RNE casts, engine.pack_matrix)
+    bit for bit -- on ordinary values, ties of the hi rounding, values beyond the plane format's range, denormal residuals and signed zeros."""
+    from frido_amd.engine import pack_matrix, plane_dtype
+    M, K = 96, 64
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, K, generator=g)
+    x[1] = x[1] * 1e4
+    x[2] = x[2] * 1e-6
+    x[3] = torch.tensor([1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, -(1.0 + 2.0 ** -11), 2048.5, 2049.5, -2050.5, 65519.9, -65520.0] * (K // 8))   # hi-plane ties
+    x[4] = torch.tensor([7e4, -7e4, 3e38, -3e38, 65504.0, -65504.0, 0.0, -0.0] * (K // 8))                                                       # range / zeros
+    x[5] = torch.tensor([2.0 ** -14, 2.0 ** -15, 6e-8, -6e-8, 2.0 ** -24, 2.0 ** -25, 1e-30, -1e-30] * (K // 8))                                  # denormal planes
+    xd = x.to(_dev())
+    b = _builder(2)
+    op = b.pack(xd.data_ptr(), 1, M, K, 0, K)
+    _run(b)
+    ref = pack_matrix(xd, 2)
+    planes = op.buf[: 2 * op.lo * 2].view(plane_dtype(2)).view(2, op.lo)      # (a pooled operand: two planes of `lo` elements)
+    assert ref.t.dtype == plane_dtype(2)
+    n = M * K
+    for plane in (0, 1):
+        got, want = planes[plane, :n].view(torch.int16), ref.t[plane, :n].view(torch.int16)
+        bad = (got != want).nonzero()
+        assert bad.numel() == 0, (plane, bad[:4].tolist(), x.flatten()[bad[:4, 0].cpu()].tolist())
+
+
 def test_two_plane_operands_saturate_instead_of_nan_and_keep_small_values():
     """r04 (advisor): the fp16 hi / lo planes of the parity mode.  (a) |v| > 65504 used to become an inf hi plane and a -inf lo
     plane, i.e. a NaN product; split_op now clamps, so the GEMM sees +-65504 -- finite, equal to the product with the clamped
