@@ -417,6 +417,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_gn_kernel(const FridoGemm d) {
         // in registers: CG_MIDBAR's barrier), `after(j)` behind slab j's MFMAs (unused in the shipped forms: a hook for experiments)
         static_for<0, TN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
+#ifdef CG_FAIRPRIO
+            // (A/B, r06) least progress first: a wave's priority falls as it works through the step's weight slabs (2, 2, 1, 1, 0, 0), so the wave
+            // that is behind wins the MFMA arbitration -- age alone lets the older wave of a SIMD finish ~500 cycles early and leaves the younger
+            // one to finish alone, at the ~60 % a lone wave reaches (tools/cg_prof.py)
+            __builtin_amdgcn_s_setprio((TN - 1 - j) >> 1);
+#endif
             if constexpr (CG_PINGPONG && j == CG_PP_K && CG_PP_K > 0) {      // the OTHER group's step boundary: this slab's weight fragment is the only read in flight
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();

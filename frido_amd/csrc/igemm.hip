@@ -612,6 +612,10 @@ __global__ __launch_bounds__((Geo<BM, BN, NS, BK, W8, KG>::NT), ((Geo<BM, BN, NS
             constexpr int RG = TN > 2 ? TN - 2 : 1;
             static_for<0, TN>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
+#ifdef IG_FAIRPRIO
+                // (A/B, r06) least progress first within a k-tile: priority 3 .. 0 over its 3 TN MFMA groups (8-wave tiles: two waves per SIMD)
+                if constexpr (NW == 8) __builtin_amdgcn_s_setprio(3 - ((V == 2 ? 0 : (V == 0 ? 1 : 2)) * TN + j) * 4 / (3 * TN));
+#endif
                 if constexpr (!(FRIDO_ABLATE & 2) && j < RG) static_for<j * NR / RG, (j + 1) * NR / RG>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     if constexpr (V == 0) fb[1 - Q][r] = lds_read128(rb + r * 16 * ROWB);
